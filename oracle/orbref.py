@@ -1,0 +1,185 @@
+"""ctypes loader for the CPU oracle (TEST INFRASTRUCTURE ONLY -- see oracle/orbref.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liborbref.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        u8p, i32p, f32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_float)
+        L.orbref_create.restype = C.c_void_p
+        L.orbref_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orbref_destroy.argtypes = [C.c_void_p]
+        L.orbref_extract.restype = C.c_int
+        L.orbref_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_int, i32p]
+        L.orbref_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.orbref_level_size.argtypes = [C.c_void_p, C.c_int, i32p, i32p]
+        L.orbref_level_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orbref_level_blurred.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orbref_level_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orbref_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orbref_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
+        L.orbref_stage_reset.argtypes = [C.c_void_p]
+        L.orbref_fast_atan2.restype = C.c_float
+        L.orbref_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orbref_fast.restype = C.c_int
+        L.orbref_fast.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orbref_fast_score.restype = C.c_int
+        L.orbref_fast_score.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orbref_resize_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orbref_gauss7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orbref_distribute.restype = C.c_int
+        L.orbref_distribute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orbref_pattern.restype = C.POINTER(C.c_int8)
+        L.orbref_hamming.restype = C.c_int
+        L.orbref_hamming.argtypes = [C.c_void_p, C.c_void_p]
+        L.orbref_three_maxima.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orbref_knn2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Extractor:
+    """Mirror of ORB_SLAM3::ORBextractor (include/ORBextractor.h:49-83) over the oracle."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.h = self.L.orbref_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        assert self.h
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+
+    def __del__(self):
+        try:
+            self.L.orbref_destroy(self.h)
+        except Exception:
+            pass
+
+    def tables(self):
+        n = self.nlevels
+        sf, isf, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        nf = np.zeros(n, np.int32); um = np.zeros(16, np.int32)
+        self.L.orbref_tables(self.h, _p(sf), _p(isf), _p(s2), _p(is2), _p(nf), _p(um))
+        return dict(sf=sf, inv_sf=isf, sig2=s2, inv_sig2=is2, nfeat=nf, umax=um)
+
+    def __call__(self, img, lap=(0, 0)):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        cap = self.nfeatures + 4 * self.nlevels + 64
+        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+        mono = C.c_int32(0)
+        n = self.L.orbref_extract(self.h, _p(img), w, h, w, int(lap[0]), int(lap[1]), _p(kps), _p(desc), cap, C.byref(mono))
+        if n < 0:
+            return n, None, None, None
+        return n, kps[:n].copy(), desc[:n].copy(), mono.value
+
+    def level_size(self, level):
+        w, h = C.c_int32(), C.c_int32()
+        self.L.orbref_level_size(self.h, level, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def level_image(self, level, blurred=False):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        f = self.L.orbref_level_blurred if blurred else self.L.orbref_level_image
+        rc = f(self.h, level, _p(out), w)
+        return out if rc == 0 else None
+
+    def level_candidates(self, level):
+        n = self.L.orbref_level_candidates(self.h, level, None, 0)
+        out = np.zeros((max(n, 1), 3), np.int32)
+        self.L.orbref_level_candidates(self.h, level, _p(out), n)
+        return out[:n]
+
+    def level_keypoints(self, level):
+        n = self.L.orbref_level_keypoints(self.h, level, None, None, 0)
+        out = np.zeros((max(n, 1), 3), np.int32); ang = np.zeros(max(n, 1), np.float32)
+        self.L.orbref_level_keypoints(self.h, level, _p(out), _p(ang), n)
+        return out[:n], ang[:n]
+
+    def stage_ms(self):
+        out = np.zeros(6, np.float64)
+        self.L.orbref_stage_ms(self.h, _p(out))
+        return dict(zip(["pyramid", "fast", "quadtree", "angle", "blur", "descriptor"], out.tolist()))
+
+    def stage_reset(self):
+        self.L.orbref_stage_reset(self.h)
+
+
+def fast(img, threshold):
+    img = np.ascontiguousarray(img, np.uint8); h, w = img.shape
+    out = np.zeros((w * h // 4 + 16, 3), np.int32)
+    n = lib().orbref_fast(_p(img), w, h, w, threshold, _p(out), out.shape[0])
+    return out[:n]
+
+
+def fast_score(img, x, y):
+    img = np.ascontiguousarray(img, np.uint8)
+    return lib().orbref_fast_score(_p(img), img.shape[1], x, y)
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8); sh, sw = src.shape
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orbref_resize_linear(_p(src), sw, sh, sw, _p(dst), dw, dh, dw)
+    return dst
+
+
+def gauss7(src):
+    src = np.ascontiguousarray(src, np.uint8); h, w = src.shape
+    dst = np.zeros_like(src)
+    lib().orbref_gauss7(_p(src), w, h, w, _p(dst), w)
+    return dst
+
+
+def distribute(xyr, minX, maxX, minY, maxY, N):
+    xyr = np.ascontiguousarray(xyr, np.int32); n = xyr.shape[0]
+    out = np.zeros(max(N + 16, 16), np.int32)
+    m = lib().orbref_distribute(_p(xyr), n, minX, maxX, minY, maxY, N, _p(out), out.shape[0])
+    return out[:m]
+
+
+def pattern():
+    return np.ctypeslib.as_array(lib().orbref_pattern(), shape=(1024,)).copy()
+
+
+def hamming(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().orbref_hamming(_p(a), _p(b))
+
+
+def three_maxima(counts):
+    c = np.ascontiguousarray(counts, np.int32); out = np.zeros(3, np.int32)
+    lib().orbref_three_maxima(_p(c), c.shape[0], _p(out))
+    return out
+
+
+def knn2(q, t):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    idx = np.zeros((q.shape[0], 2), np.int32); dist = np.zeros((q.shape[0], 2), np.int32)
+    lib().orbref_knn2(_p(q), q.shape[0], _p(t), t.shape[0], _p(idx), _p(dist))
+    return idx, dist

@@ -1,0 +1,32 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    """The product package (directory name has a hyphen, so import it by string)."""
+    return importlib.import_module("orb-slam3_amd")
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return importlib.import_module("orb-slam3_amd.synth")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import orbref
+    orbref.lib()
+    return orbref
