@@ -1,0 +1,103 @@
+/* orbx.h -- C ABI of the MI355X-native ORB extractor (drop-in for ORB_SLAM3::ORBextractor).
+ *
+ * The reference has no FFI layer: its boundary is the C++ class used by Frame/Tracking
+ * (include/ORBextractor.h:49-83, src/ORBextractor.cc:468-571,1534-1659).  The C++ facade
+ * orb-slam3_amd/facade/ORBextractor.h re-exposes that class over these entry points.
+ *
+ * Conventions: no exceptions cross this ABI; negative return = error (ORBX_E_*); all output buffers are
+ * caller-owned; a handle is NOT thread-safe (one per concurrent caller, exactly like the reference's
+ * stateful extractor); the device is selected at create time.  There is NO CPU fallback:
+ * every entry point that computes fails with ORBX_E_HIP when no gfx950 device is usable.
+ */
+#ifndef ORBX_H_
+#define ORBX_H_
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orbx orbx_t;
+
+/* == cv::KeyPoint memory layout, 28 bytes (replaces std::vector<cv::KeyPoint>& of ORBextractor.h:57-59) */
+typedef struct { float x, y, size, angle, response; int32_t octave, class_id; } orbx_kp_t;
+
+enum {
+    ORBX_OK = 0,
+    ORBX_E_EMPTY = -1,        /* empty image: the reference's `return -1` (ORBextractor.cc:1538-1539) */
+    ORBX_E_INVALID = -2,      /* bad argument */
+    ORBX_E_CAPACITY = -3,     /* caller buffer / configured batch too small */
+    ORBX_E_TOO_SMALL = -4,    /* a pyramid level is narrower than one 35-px FAST cell (reference divides by 0) */
+    ORBX_E_HIP = -5,          /* HIP runtime error or no device; orbx_last_error() has the text */
+    ORBX_E_UNSUPPORTED = -6,  /* size limit of the on-chip quadtree / packed coordinates exceeded */
+    ORBX_E_INTERNAL = -7      /* device-side overflow flag raised (never expected) */
+};
+
+/* flags for image / result pointers */
+enum { ORBX_HOST = 0, ORBX_DEVICE = 1 };
+
+/* replaces ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ * (ORBextractor.cc:468-571).  max_w/max_h/max_batch size the device-resident pyramid and scratch. */
+int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th,
+                int device_id, int max_w, int max_h, int max_batch);
+void orbx_destroy(orbx_t*);
+const char* orbx_last_error(void);
+
+/* upper bound of keypoints one image can return (>= nfeatures + 3*nlevels, see DistributeOctTree) */
+int orbx_max_keypoints(const orbx_t*);
+
+/* replaces ORBextractor::operator() (ORBextractor.cc:1534-1659) for one image.
+ * img: host pointer, row stride in bytes.  kps/desc: host buffers with room for `cap` entries
+ * (desc is cap x 32 bytes).  Returns n >= 0 keypoints, writes *mono_index (the reference's return value). */
+int orbx_extract(orbx_t*, const uint8_t* img, int w, int h, int stride, int lap0, int lap1,
+                 orbx_kp_t* kps, uint8_t* desc, int cap, int* mono_index);
+
+/* frame-parallel batch (all images w x h, same stride).  imgs[i] are host or device pointers
+ * (img_space = ORBX_HOST / ORBX_DEVICE).  lap01 = 2 ints per image or NULL for {0,0}.
+ * Results stay on the device (orbx_result_*); n_out/mono_out (host, may be NULL) receive per-image counts
+ * -- passing them forces a stream sync.  Returns 0 or ORBX_E_*. */
+int orbx_extract_batch(orbx_t*, const uint8_t* const* imgs, int img_space, int nimg, int w, int h, int stride,
+                       const int* lap01, int* n_out, int* mono_out);
+/* enqueue only (no sync, no D2H): the timed body of bench.py.  Same arguments as above minus outputs. */
+int orbx_extract_batch_async(orbx_t*, const uint8_t* const* imgs, int img_space, int nimg, int w, int h, int stride,
+                             const int* lap01);
+int orbx_sync(orbx_t*);
+
+/* device-resident results of the last batch: kps = [max_batch][cap] orbx_kp_t, desc = [max_batch][cap][32],
+ * counts = [max_batch] int32 (n), monos = [max_batch] int32; cap = orbx_max_keypoints(). */
+int orbx_result_device(const orbx_t*, const orbx_kp_t** kps, const uint8_t** desc, const int32_t** counts,
+                       const int32_t** monos, int* cap);
+/* copy image `i` of the last batch to host buffers; returns n or ORBX_E_* */
+int orbx_result_fetch(orbx_t*, int i, orbx_kp_t* kps, uint8_t* desc, int cap, int* mono_index);
+
+/* mvImagePyramid back-door (include/ORBextractor.h:83; used by Frame::ComputeStereoMatches, Frame.cc:1168) */
+int orbx_level_size(const orbx_t*, int level, int* w, int* h);
+int orbx_level_image(orbx_t*, int frame, int level, int blurred, uint8_t* dst, int dst_stride);
+/* GetScaleFactors & co (include/ORBextractor.h:61-79) */
+void orbx_scale_tables(const orbx_t*, float* sf, float* inv_sf, float* sig2, float* inv_sig2);
+int orbx_features_per_level(const orbx_t*, int* nfeat);
+
+/* stage introspection for parity tests: FAST candidates handed to the quadtree for (frame, level), in
+ * the reference's vToDistributeKeys order, as (x,y,response) int triples relative to (16,16). */
+int orbx_level_candidates(orbx_t*, int frame, int level, int32_t* xyr, int cap);
+/* keypoints chosen by the quadtree for (frame, level) in list order: (x,y,response) in level coordinates */
+int orbx_level_selected(orbx_t*, int frame, int level, int32_t* xyr, int cap);
+
+/* timing: HIP events around the most recent async batch, per kernel group [ms]:
+ * 0 pyramid(resize), 1 fast, 2 quadtree, 3 slots, 4 blur, 5 orient+descriptor, 6 total */
+int orbx_last_timings(orbx_t*, float* ms7);
+/* algorithmic bytes of the pyramid+FAST pass for one frame of the current geometry */
+int64_t orbx_algorithmic_bytes(const orbx_t*, int64_t* fused_lower_bound);
+void* orbx_stream(const orbx_t*);     /* hipStream_t the kernels are launched on */
+
+/* plain device-memory helpers so callers need no HIP bindings of their own */
+void* orbx_dev_alloc(size_t bytes);
+void orbx_dev_free(void*);
+int orbx_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int orbx_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int orbx_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,498 @@
+// orbx_api.hip -- C ABI (include/orbx.h) over the gfx950 extractor kernels.
+// Host side: replays the reference constructor tables and per-image geometry in the same float arithmetic
+// (ORBextractor.cc:468-571, 1038-1106, 1664-1672), owns the device-resident pyramid/scratch, launches the
+// pipeline on one HIP stream.  No CPU fallback: every failure surfaces as ORBX_E_*.
+#include "../../include/orbx.h"
+#include "orbx_kernels.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace orbxk;
+
+static thread_local std::string g_err;
+static void set_err(const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err("%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return ORBX_E_HIP; } } while (0)
+
+static const int8_t kPattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+static inline int cv_round_f(float v) { return (int)lrintf(v); }
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+struct orbx {
+    int nfeatures, nlevels, iniTh, minTh, device, maxW, maxH, maxBatch;
+    double scaleFactor;
+    std::vector<float> sf, invsf, sig2, invsig2;
+    std::vector<int> nfeat;
+    Umax umax;
+    // geometry of the current image size
+    int curW = 0, curH = 0;
+    Geom g;
+    std::vector<CellInfo> cells;
+    std::vector<TileInfo> tiles;
+    std::vector<RzTab> xt, yt;
+    int64_t algBytes = 0, fusedBytes = 0;
+    size_t qtLds = 0;
+    // device
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    u8 *dPyr = nullptr, *dBlur = nullptr, *dL0 = nullptr;
+    const u8** dL0Ptr = nullptr;
+    CellInfo* dCells = nullptr; TileInfo* dTiles = nullptr; RzTab *dXt = nullptr, *dYt = nullptr;
+    u32 *dCandCnt = nullptr, *dCandEnt = nullptr, *dSel = nullptr, *dSelCnt = nullptr;
+    u16* dKpNode = nullptr;
+    KpOut* dKps = nullptr; u8* dDesc = nullptr; KpWork* dWork = nullptr;
+    int *dN = nullptr, *dMono = nullptr, *dLap = nullptr, *dErr = nullptr;
+    int8_t* dPattern = nullptr;
+    size_t capL0 = 0, capPyr = 0, capCells = 0, capTiles = 0, capXt = 0, capYt = 0, capCandCnt = 0, capCandEnt = 0, capSel = 0;
+    int lastBatch = 0;
+    int l0pitch = 0;
+    std::vector<const u8*> hL0Ptr;
+    std::vector<int> hLap;
+    bool timed = false;
+};
+
+template <class T> static int ensure(T** p, size_t* cap, size_t need) {
+    if (need <= *cap && *p) return 0;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    HIPCHK(hipMalloc((void**)p, need * sizeof(T)));
+    *cap = need;
+    return 0;
+}
+
+// ---- geometry (replays ORBextractor.cc:1669, 1053-1106, 695-699 in the reference's float arithmetic)
+static int build_geometry(orbx* o, int w, int h) {
+    if (o->curW == w && o->curH == h) return 0;
+    if (w > o->maxW || h > o->maxH) { set_err("image %dx%d exceeds the configured maximum %dx%d", w, h, o->maxW, o->maxH); return ORBX_E_CAPACITY; }
+    Geom& g = o->g;
+    memset(&g, 0, sizeof g);
+    const int L = o->nlevels;
+    g.nlevels = L; g.w0 = w; g.h0 = h; g.iniTh = o->iniTh; g.minTh = o->minTh; g.lowTh = std::min(o->iniTh, o->minTh);
+    o->cells.clear(); o->tiles.clear(); o->xt.clear(); o->yt.clear();
+    size_t off = 0;
+    int totalSlots = 0, totalSel = 0, maxN = 0;
+    int64_t sumAll = 0, sumSrc = 0, sumDst = 0;
+    for (int l = 0; l < L; ++l) {
+        LevelDesc& D = g.lv[l];
+        const float scale = o->invsf[l];
+        D.w = cv_round_f((float)w * scale); D.h = cv_round_f((float)h * scale);
+        if (D.w > 4095 || D.h > 4095) { set_err("level %d is %dx%d: packed candidates hold 12-bit coordinates", l, D.w, D.h); return ORBX_E_UNSUPPORTED; }
+        D.pitch = align_up(D.w, 64);
+        D.off = (int)off;
+        off += (size_t)align_up(D.pitch * D.h, 256);
+        D.sf = o->sf[l];
+        D.patch = (float)(int)(31 * o->sf[l]);
+        D.N = o->nfeat[l];
+        sumAll += (int64_t)D.w * D.h;
+        if (l < L - 1) sumSrc += (int64_t)D.w * D.h;
+        if (l > 0) sumDst += (int64_t)D.w * D.h;
+        // FAST cell grid
+        const int minB = 16, maxBX = D.w - 16, maxBY = D.h - 16;
+        const float width = (float)(maxBX - minB), height = (float)(maxBY - minB);
+        const float W = 35;
+        const int nCols = (int)(width / W), nRows = (int)(height / W);
+        if (nCols < 1 || nRows < 1) { set_err("level %d (%dx%d) is smaller than one FAST cell", l, D.w, D.h); return ORBX_E_TOO_SMALL; }
+        const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+        D.cellBase = (int)o->cells.size();
+        D.slotBase = totalSlots;
+        D.slotCap = ((wCell + 1) / 2) * ((hCell + 1) / 2);
+        for (int i = 0; i < nRows; ++i) {
+            const float iniY = (float)(minB + i * hCell);
+            float maxY = iniY + hCell + 6;
+            if (iniY >= maxBY - 3) continue;
+            if (maxY > maxBY) maxY = (float)maxBY;
+            for (int j = 0; j < nCols; ++j) {
+                const float iniX = (float)(minB + j * wCell);
+                float maxX = iniX + wCell + 6;
+                if (iniX >= maxBX - 6) continue;
+                if (maxX > maxBX) maxX = (float)maxBX;
+                CellInfo c;
+                c.level = (short)l; c.x0 = (short)iniX; c.y0 = (short)iniY;
+                c.cw = (short)((int)maxX - (int)iniX); c.ch = (short)((int)maxY - (int)iniY);
+                c.addx = (short)(j * wCell); c.addy = (short)(i * hCell); c.pad = 0;
+                c.cnt = (int)o->cells.size();
+                c.slot = totalSlots;
+                if ((int)c.cw * c.ch > ORBX_FAST_TILE) { set_err("FAST cell %dx%d exceeds the LDS tile", c.cw, c.ch); return ORBX_E_UNSUPPORTED; }
+                totalSlots += D.slotCap;
+                o->cells.push_back(c);
+            }
+        }
+        D.nCells = (int)o->cells.size() - D.cellBase;
+        if (totalSlots - D.slotBase >= (1 << 24)) { set_err("level %d has too many candidate slots", l); return ORBX_E_UNSUPPORTED; }
+        // quadtree roots (ORBextractor.cc:695-699)
+        D.qtW = maxBX - minB; D.qtH = maxBY - minB;
+        D.nIni = (int)std::round(static_cast<float>(D.qtW) / D.qtH);
+        if (D.nIni < 1 || D.nIni > 16) { set_err("aspect ratio of level %d unsupported (nIni=%d; the reference divides by zero for nIni=0)", l, D.nIni); return ORBX_E_UNSUPPORTED; }
+        D.hX = static_cast<float>(D.qtW) / D.nIni;
+        D.selBase = totalSel;
+        D.selCap = std::max(D.N + 3, 4 * D.nIni) + 1;
+        totalSel += D.selCap;
+        maxN = std::max(maxN, std::max(D.N, 4 * D.nIni));
+        // blur tiles
+        for (int ty = 0; ty < D.h; ty += BL_TH)
+            for (int tx = 0; tx < D.w; tx += BL_TW) o->tiles.push_back(TileInfo{(short)l, (short)tx, (short)ty, 0});
+        // resize taps from level l-1
+        D.rzx = (int)o->xt.size(); D.rzy = (int)o->yt.size();
+        if (l > 0) {
+            const LevelDesc& S = g.lv[l - 1];
+            const double scale_x = 1.0 / ((double)D.w / S.w), scale_y = 1.0 / ((double)D.h / S.h);
+            auto sat = [](float v) { int r = (int)lrintf(v); return (short)std::min(32767, std::max(-32768, r)); };
+            for (int dx = 0; dx < D.w; ++dx) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = (int)floorf(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx >= S.w - 1) { fx = 0; sx = S.w - 1; }
+                o->xt.push_back(RzTab{sx, sat((1.f - fx) * 2048.f), sat(fx * 2048.f)});
+            }
+            for (int dy = 0; dy < D.h; ++dy) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                int sy = (int)floorf(fy);
+                fy -= sy;
+                o->yt.push_back(RzTab{sy, sat((1.f - fy) * 2048.f), sat(fy * 2048.f)});
+            }
+        }
+    }
+    g.pyrFrameBytes = off;
+    g.totalCells = (int)o->cells.size();
+    g.totalSlots = totalSlots;
+    g.totalSel = totalSel;
+    g.kpCap = totalSel;
+    g.nodeCap = 2 * maxN + 64;
+    int sc = 1; while (sc < maxN + 8) sc <<= 1;
+    g.sortCap = sc;
+    if (g.nodeCap > 65000) { set_err("nfeatures per level %d too large for 16-bit node ids", maxN); return ORBX_E_UNSUPPORTED; }
+    o->qtLds = (size_t)g.sortCap * 8 + (size_t)g.nodeCap * 56 + 64;
+    if (o->qtLds > 160 * 1024 - 512) { set_err("quadtree for %d features/level needs %zu B of LDS (> 160 KiB)", maxN, o->qtLds); return ORBX_E_UNSUPPORTED; }
+    o->algBytes = sumSrc + sumDst + sumAll;      // read L0..L6 + write L1..L7 + read L0..L7
+    o->fusedBytes = sumSrc + sumDst;
+    o->l0pitch = align_up(w, 64);
+
+    const size_t B = (size_t)o->maxBatch;
+    if (ensure(&o->dPyr, &o->capPyr, off * B)) return ORBX_E_HIP;
+    { size_t c2 = 0; u8* old = o->dBlur; if (old) (void)hipFree(old); o->dBlur = nullptr; if (ensure(&o->dBlur, &c2, off * B)) return ORBX_E_HIP; }
+    if (ensure(&o->dL0, &o->capL0, (size_t)o->l0pitch * h * B)) return ORBX_E_HIP;
+    if (ensure(&o->dCells, &o->capCells, o->cells.size())) return ORBX_E_HIP;
+    if (ensure(&o->dTiles, &o->capTiles, o->tiles.size())) return ORBX_E_HIP;
+    if (ensure(&o->dXt, &o->capXt, std::max<size_t>(1, o->xt.size()))) return ORBX_E_HIP;
+    if (ensure(&o->dYt, &o->capYt, std::max<size_t>(1, o->yt.size()))) return ORBX_E_HIP;
+    if (ensure(&o->dCandCnt, &o->capCandCnt, (size_t)g.totalCells * B)) return ORBX_E_HIP;
+    { size_t c2 = 0; if (o->dKpNode) (void)hipFree(o->dKpNode); o->dKpNode = nullptr; if (ensure(&o->dKpNode, &c2, (size_t)g.totalSlots * B)) return ORBX_E_HIP; }
+    if (ensure(&o->dCandEnt, &o->capCandEnt, (size_t)g.totalSlots * B)) return ORBX_E_HIP;
+    if (ensure(&o->dSel, &o->capSel, (size_t)g.totalSel * B)) return ORBX_E_HIP;
+    {
+        if (o->dKps) (void)hipFree(o->dKps); if (o->dDesc) (void)hipFree(o->dDesc); if (o->dWork) (void)hipFree(o->dWork);
+        o->dKps = nullptr; o->dDesc = nullptr; o->dWork = nullptr;
+        HIPCHK(hipMalloc((void**)&o->dKps, sizeof(KpOut) * g.kpCap * B));
+        HIPCHK(hipMalloc((void**)&o->dDesc, (size_t)32 * g.kpCap * B));
+        HIPCHK(hipMalloc((void**)&o->dWork, sizeof(KpWork) * g.kpCap * B));
+    }
+    HIPCHK(hipMemcpy(o->dCells, o->cells.data(), o->cells.size() * sizeof(CellInfo), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(o->dTiles, o->tiles.data(), o->tiles.size() * sizeof(TileInfo), hipMemcpyHostToDevice));
+    if (!o->xt.empty()) HIPCHK(hipMemcpy(o->dXt, o->xt.data(), o->xt.size() * sizeof(RzTab), hipMemcpyHostToDevice));
+    if (!o->yt.empty()) HIPCHK(hipMemcpy(o->dYt, o->yt.data(), o->yt.size() * sizeof(RzTab), hipMemcpyHostToDevice));
+    HIPCHK(hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->qtLds));
+    o->curW = w; o->curH = h;
+    return 0;
+}
+
+extern "C" {
+
+const char* orbx_last_error(void) { return g_err.c_str(); }
+
+int orbx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th,
+                int device_id, int max_w, int max_h, int max_batch) {
+    if (!out) return ORBX_E_INVALID;
+    *out = nullptr;
+    if (nfeatures < 1 || nlevels < 1 || nlevels > 12 || !(scale_factor > 1.0f) || max_batch < 1 || max_w < 1 || max_h < 1 ||
+        ini_th < 1 || ini_th > 255 || min_th < 1 || min_th > 255) {
+        set_err("invalid extractor parameters"); return ORBX_E_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_err("no HIP device: the MI355X extractor has no CPU fallback"); return ORBX_E_HIP; }
+    if (device_id < 0 || device_id >= ndev) { set_err("device %d out of range (%d devices)", device_id, ndev); return ORBX_E_INVALID; }
+    HIPCHK(hipSetDevice(device_id));
+    orbx* o = new orbx;
+    o->nfeatures = nfeatures; o->nlevels = nlevels; o->iniTh = ini_th; o->minTh = min_th; o->device = device_id;
+    o->maxW = max_w; o->maxH = max_h; o->maxBatch = max_batch;
+    o->scaleFactor = scale_factor;                              // double member initialised from float (ORBextractor.h:96)
+    const int L = nlevels;
+    o->sf.resize(L); o->sig2.resize(L); o->invsf.resize(L); o->invsig2.resize(L); o->nfeat.resize(L);
+    o->sf[0] = 1.0f; o->sig2[0] = 1.0f;
+    for (int i = 1; i < L; ++i) { o->sf[i] = (float)(o->sf[i - 1] * o->scaleFactor); o->sig2[i] = o->sf[i] * o->sf[i]; }
+    for (int i = 0; i < L; ++i) { o->invsf[i] = 1.0f / o->sf[i]; o->invsig2[i] = 1.0f / o->sig2[i]; }
+    float factor = (float)(1.0f / o->scaleFactor);
+    float nDesired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)L));
+    int sum = 0;
+    for (int l = 0; l < L - 1; ++l) { o->nfeat[l] = cv_round_f(nDesired); sum += o->nfeat[l]; nDesired *= factor; }
+    o->nfeat[L - 1] = std::max(nfeatures - sum, 0);
+    {   // umax (ORBextractor.cc:542-570)
+        int* um = o->umax.v;
+        int v, v0, vmax = (int)floorf(15 * sqrtf(2.f) / 2 + 1), vmin = (int)ceilf(15 * sqrtf(2.f) / 2);
+        for (v = 0; v <= vmax; ++v) um[v] = (int)lrint(std::sqrt(225.0 - v * v));
+        for (v = 15, v0 = 0; v >= vmin; --v) { while (um[v0] == um[v0 + 1]) ++v0; um[v] = v0; ++v0; }
+    }
+    int rc = ORBX_OK;
+    do {
+        if (hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipStreamCreate failed"); break; }
+        for (auto& e : o->ev) if (hipEventCreate(&e) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); break; }
+        if (rc) break;
+        const size_t B = max_batch;
+        if (hipMalloc((void**)&o->dL0Ptr, sizeof(u8*) * B) != hipSuccess || hipMalloc((void**)&o->dSelCnt, sizeof(u32) * 12 * B) != hipSuccess ||
+            hipMalloc((void**)&o->dN, sizeof(int) * B) != hipSuccess || hipMalloc((void**)&o->dMono, sizeof(int) * B) != hipSuccess ||
+            hipMalloc((void**)&o->dLap, sizeof(int) * 2 * B) != hipSuccess || hipMalloc((void**)&o->dErr, sizeof(int)) != hipSuccess ||
+            hipMalloc((void**)&o->dPattern, 1024) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
+        if (hipMemcpy(o->dPattern, kPattern, 1024, hipMemcpyHostToDevice) != hipSuccess || hipMemset(o->dErr, 0, sizeof(int)) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMemcpy failed"); break; }
+        o->hL0Ptr.resize(B); o->hLap.resize(2 * B);
+        rc = build_geometry(o, max_w, max_h);
+    } while (0);
+    if (rc) { orbx_destroy(o); return rc; }
+    *out = o;
+    return ORBX_OK;
+}
+
+void orbx_destroy(orbx_t* o) {
+    if (!o) return;
+    (void)hipSetDevice(o->device);
+    if (o->stream) (void)hipStreamSynchronize(o->stream);
+    void* ptrs[] = {o->dPyr, o->dBlur, o->dL0, (void*)o->dL0Ptr, o->dCells, o->dTiles, o->dXt, o->dYt, o->dCandCnt, o->dCandEnt,
+                    o->dSel, o->dSelCnt, o->dKpNode, o->dKps, o->dDesc, o->dWork, o->dN, o->dMono, o->dLap, o->dErr, o->dPattern};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& e : o->ev) if (e) (void)hipEventDestroy(e);
+    if (o->stream) (void)hipStreamDestroy(o->stream);
+    delete o;
+}
+
+int orbx_max_keypoints(const orbx_t* o) { return o ? o->g.kpCap : ORBX_E_INVALID; }
+
+int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_space, int nimg, int w, int h, int stride,
+                             const int* lap01) {
+    if (!o || !imgs || nimg < 1) return ORBX_E_INVALID;
+    if (nimg > o->maxBatch) { set_err("batch %d exceeds max_batch %d", nimg, o->maxBatch); return ORBX_E_CAPACITY; }
+    if (w <= 0 || h <= 0) return ORBX_E_EMPTY;
+    for (int i = 0; i < nimg; ++i) if (!imgs[i]) return ORBX_E_EMPTY;
+    if (stride < w) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    int rc = build_geometry(o, w, h);
+    if (rc) return rc;
+    const Geom& g = o->g;
+    hipStream_t st = o->stream;
+    int l0pitch;
+    if (img_space == ORBX_DEVICE) {
+        for (int i = 0; i < nimg; ++i) o->hL0Ptr[i] = imgs[i];
+        l0pitch = stride;
+    } else {
+        for (int i = 0; i < nimg; ++i) {
+            u8* d = o->dL0 + (size_t)i * o->l0pitch * h;
+            HIPCHK(hipMemcpy2DAsync(d, o->l0pitch, imgs[i], stride, w, h, hipMemcpyHostToDevice, st));
+            o->hL0Ptr[i] = d;
+        }
+        l0pitch = o->l0pitch;
+    }
+    for (int i = 0; i < nimg; ++i) { o->hLap[2 * i] = lap01 ? lap01[2 * i] : 0; o->hLap[2 * i + 1] = lap01 ? lap01[2 * i + 1] : 0; }
+    HIPCHK(hipMemcpyAsync((void*)o->dL0Ptr, o->hL0Ptr.data(), sizeof(u8*) * nimg, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(o->dLap, o->hLap.data(), sizeof(int) * 2 * nimg, hipMemcpyHostToDevice, st));
+
+    HIPCHK(hipEventRecord(o->ev[0], st));
+    for (int l = 1; l < g.nlevels; ++l) {
+        dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, nimg), block(64, 4);
+        hipLaunchKernelGGL(k_resize, grid, block, 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, l, o->dXt, o->dYt);
+    }
+    HIPCHK(hipEventRecord(o->ev[1], st));
+    hipLaunchKernelGGL(k_fast, dim3(g.totalCells, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dCells,
+                       o->dCandCnt, o->dCandEnt, o->dErr);
+    HIPCHK(hipEventRecord(o->ev[2], st));
+    hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, nimg), dim3(256), o->qtLds, st, g, o->dCells, o->dCandCnt, o->dCandEnt,
+                       o->dKpNode, o->dSel, o->dSelCnt, o->dErr);
+    HIPCHK(hipEventRecord(o->ev[3], st));
+    hipLaunchKernelGGL(k_slots, dim3(nimg), dim3(256), 0, st, g, o->dSel, o->dSelCnt, o->dLap, o->dKps, o->dWork, o->dN, o->dMono);
+    HIPCHK(hipEventRecord(o->ev[4], st));
+    hipLaunchKernelGGL(k_blur, dim3((unsigned)o->tiles.size(), nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur, o->dTiles);
+    HIPCHK(hipEventRecord(o->ev[5], st));
+    hipLaunchKernelGGL(k_orient_desc, dim3((g.kpCap + 3) / 4, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
+                       o->dWork, o->dN, o->dKps, o->dDesc, o->dPattern, o->umax);
+    HIPCHK(hipEventRecord(o->ev[6], st));
+    HIPCHK(hipGetLastError());
+    o->lastBatch = nimg;
+    o->timed = true;
+    return ORBX_OK;
+}
+
+int orbx_sync(orbx_t* o) {
+    if (!o) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    HIPCHK(hipStreamSynchronize(o->stream));
+    int e = 0;
+    HIPCHK(hipMemcpy(&e, o->dErr, sizeof(int), hipMemcpyDeviceToHost));
+    if (e) { set_err("device-side overflow flag %d", e); (void)hipMemset(o->dErr, 0, sizeof(int)); return ORBX_E_INTERNAL; }
+    return ORBX_OK;
+}
+
+int orbx_extract_batch(orbx_t* o, const uint8_t* const* imgs, int img_space, int nimg, int w, int h, int stride,
+                       const int* lap01, int* n_out, int* mono_out) {
+    int rc = orbx_extract_batch_async(o, imgs, img_space, nimg, w, h, stride, lap01);
+    if (rc) return rc;
+    rc = orbx_sync(o);
+    if (rc) return rc;
+    if (n_out) HIPCHK(hipMemcpy(n_out, o->dN, sizeof(int) * nimg, hipMemcpyDeviceToHost));
+    if (mono_out) HIPCHK(hipMemcpy(mono_out, o->dMono, sizeof(int) * nimg, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int orbx_result_device(const orbx_t* o, const orbx_kp_t** kps, const uint8_t** desc, const int32_t** counts,
+                       const int32_t** monos, int* cap) {
+    if (!o) return ORBX_E_INVALID;
+    if (kps) *kps = (const orbx_kp_t*)o->dKps;
+    if (desc) *desc = o->dDesc;
+    if (counts) *counts = o->dN;
+    if (monos) *monos = o->dMono;
+    if (cap) *cap = o->g.kpCap;
+    return ORBX_OK;
+}
+
+int orbx_result_fetch(orbx_t* o, int i, orbx_kp_t* kps, uint8_t* desc, int cap, int* mono_index) {
+    if (!o || i < 0 || i >= o->lastBatch) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    int rc = orbx_sync(o);
+    if (rc) return rc;
+    int n = 0, mono = 0;
+    HIPCHK(hipMemcpy(&n, o->dN + i, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&mono, o->dMono + i, sizeof(int), hipMemcpyDeviceToHost));
+    if (n > cap) { set_err("%d keypoints exceed caller capacity %d", n, cap); return ORBX_E_CAPACITY; }
+    if (n > 0) {
+        if (kps) HIPCHK(hipMemcpy(kps, o->dKps + (size_t)i * o->g.kpCap, sizeof(KpOut) * n, hipMemcpyDeviceToHost));
+        if (desc) HIPCHK(hipMemcpy(desc, o->dDesc + (size_t)i * o->g.kpCap * 32, (size_t)32 * n, hipMemcpyDeviceToHost));
+    }
+    if (mono_index) *mono_index = mono;
+    return n;
+}
+
+int orbx_extract(orbx_t* o, const uint8_t* img, int w, int h, int stride, int lap0, int lap1,
+                 orbx_kp_t* kps, uint8_t* desc, int cap, int* mono_index) {
+    if (!o) return ORBX_E_INVALID;
+    if (!img || w <= 0 || h <= 0) return ORBX_E_EMPTY;
+    const int lap[2] = {lap0, lap1};
+    int rc = orbx_extract_batch_async(o, &img, ORBX_HOST, 1, w, h, stride, lap);
+    if (rc) return rc;
+    return orbx_result_fetch(o, 0, kps, desc, cap, mono_index);
+}
+
+int orbx_level_size(const orbx_t* o, int level, int* w, int* h) {
+    if (!o || level < 0 || level >= o->nlevels || !o->curW) return ORBX_E_INVALID;
+    *w = o->g.lv[level].w; *h = o->g.lv[level].h;
+    return ORBX_OK;
+}
+
+int orbx_level_image(orbx_t* o, int frame, int level, int blurred, uint8_t* dst, int dst_stride) {
+    if (!o || frame < 0 || frame >= o->lastBatch || level < 0 || level >= o->nlevels) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    HIPCHK(hipStreamSynchronize(o->stream));
+    const LevelDesc& D = o->g.lv[level];
+    if (level == 0 && !blurred) {
+        // level 0 lives wherever the caller's image (or its staged copy) is
+        const u8* src = o->hL0Ptr[frame];
+        int pitch = (src >= o->dL0 && src < o->dL0 + o->capL0) ? o->l0pitch : 0;
+        if (!pitch) { set_err("level 0 of a device-resident input is the caller's own buffer"); return ORBX_E_INVALID; }
+        HIPCHK(hipMemcpy2D(dst, dst_stride, src, pitch, D.w, D.h, hipMemcpyDeviceToHost));
+        return ORBX_OK;
+    }
+    const u8* base = (blurred ? o->dBlur : o->dPyr) + (size_t)frame * o->g.pyrFrameBytes + D.off;
+    HIPCHK(hipMemcpy2D(dst, dst_stride, base, D.pitch, D.w, D.h, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+void orbx_scale_tables(const orbx_t* o, float* sf, float* inv_sf, float* sig2, float* inv_sig2) {
+    for (int i = 0; i < o->nlevels; ++i) {
+        if (sf) sf[i] = o->sf[i];
+        if (inv_sf) inv_sf[i] = o->invsf[i];
+        if (sig2) sig2[i] = o->sig2[i];
+        if (inv_sig2) inv_sig2[i] = o->invsig2[i];
+    }
+}
+
+int orbx_features_per_level(const orbx_t* o, int* nfeat) {
+    if (!o) return ORBX_E_INVALID;
+    for (int i = 0; i < o->nlevels; ++i) nfeat[i] = o->nfeat[i];
+    return o->nlevels;
+}
+
+int orbx_level_candidates(orbx_t* o, int frame, int level, int32_t* xyr, int cap) {
+    if (!o || frame < 0 || frame >= o->lastBatch || level < 0 || level >= o->nlevels) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    HIPCHK(hipStreamSynchronize(o->stream));
+    const Geom& g = o->g;
+    const LevelDesc& D = g.lv[level];
+    std::vector<u32> cnt(D.nCells), ent((size_t)D.nCells * D.slotCap);
+    HIPCHK(hipMemcpy(cnt.data(), o->dCandCnt + (size_t)frame * g.totalCells + D.cellBase, sizeof(u32) * D.nCells, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ent.data(), o->dCandEnt + (size_t)frame * g.totalSlots + D.slotBase, sizeof(u32) * ent.size(), hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int c = 0; c < D.nCells; ++c)
+        for (u32 k = 0; k < cnt[c]; ++k, ++n)
+            if (n < cap) {
+                const u32 e = ent[(size_t)c * D.slotCap + k];
+                xyr[3 * n] = (int)(e & 0xFFF); xyr[3 * n + 1] = (int)((e >> 12) & 0xFFF); xyr[3 * n + 2] = (int)(e >> 24);
+            }
+    return n;
+}
+
+int orbx_level_selected(orbx_t* o, int frame, int level, int32_t* xyr, int cap) {
+    if (!o || frame < 0 || frame >= o->lastBatch || level < 0 || level >= o->nlevels) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    HIPCHK(hipStreamSynchronize(o->stream));
+    const Geom& g = o->g;
+    const LevelDesc& D = g.lv[level];
+    u32 n = 0;
+    HIPCHK(hipMemcpy(&n, o->dSelCnt + frame * g.nlevels + level, sizeof(u32), hipMemcpyDeviceToHost));
+    std::vector<u32> e(n);
+    if (n) HIPCHK(hipMemcpy(e.data(), o->dSel + (size_t)frame * g.totalSel + D.selBase, sizeof(u32) * n, hipMemcpyDeviceToHost));
+    for (u32 i = 0; i < n && (int)i < cap; ++i) {
+        xyr[3 * i] = (int)(e[i] & 0xFFF) + 16; xyr[3 * i + 1] = (int)((e[i] >> 12) & 0xFFF) + 16; xyr[3 * i + 2] = (int)(e[i] >> 24);
+    }
+    return (int)n;
+}
+
+int orbx_last_timings(orbx_t* o, float* ms7) {
+    if (!o || !o->timed) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    HIPCHK(hipStreamSynchronize(o->stream));
+    for (int i = 0; i < 6; ++i) HIPCHK(hipEventElapsedTime(&ms7[i], o->ev[i], o->ev[i + 1]));
+    HIPCHK(hipEventElapsedTime(&ms7[6], o->ev[0], o->ev[6]));
+    return ORBX_OK;
+}
+
+int64_t orbx_algorithmic_bytes(const orbx_t* o, int64_t* fused_lower_bound) {
+    if (!o) return ORBX_E_INVALID;
+    if (fused_lower_bound) *fused_lower_bound = o->fusedBytes;
+    return o->algBytes;
+}
+
+void* orbx_stream(const orbx_t* o) { return o ? (void*)o->stream : nullptr; }
+
+void* orbx_dev_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { set_err("hipMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+void orbx_dev_free(void* p) { if (p) (void)hipFree(p); }
+int orbx_memcpy_h2d(void* dst, const void* src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return ORBX_OK; }
+int orbx_memcpy_d2h(void* dst, const void* src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return ORBX_OK; }
+
+}  // extern "C"

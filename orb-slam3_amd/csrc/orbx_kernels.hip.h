@@ -1,0 +1,644 @@
+// orbx_kernels.hip.h -- hand-written gfx950 kernels of the ORB extractor.
+//
+// Pipeline per batch (all kernels are launched over (work-item, frame) so a batch fills the chip):
+//   k_resize      x(L-1)  level l-1 -> level l, OpenCV INTER_LINEAR fixed point  (ORBextractor.cc:1664-1717)
+//   k_fast        x1      per 35-px cell: FAST-9/16 score, 3x3 NMS, ini/min threshold   (:1038-1143)
+//   k_quadtree    x1      DistributeOctTree per (frame, level)                            (:688-1034)
+//   k_slots       x1      octave/size fix-up, level-0 scaling, lapping partition          (:1161-1176,1633-1655)
+//   k_blur        x1      7x7 Gaussian, sigma 2, reflect-101, bit-exact fixed point       (:1606-1614)
+//   k_orient_desc x1      IC_Angle + 256-bit steered BRIEF, one wavefront per keypoint    (:91-203)
+// Integer / byte work throughout: no MFMA (HBM-bound stencils, ALU/LDS-bound descriptors).
+// Compiled with -ffp-contract=off so the few float expressions evaluate exactly as the reference writes them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace orbxk {
+
+typedef uint32_t u32;
+typedef uint16_t u16;
+typedef uint8_t u8;
+
+struct RzTab { int s; short a0, a1; };                     // source index + two Q11 taps (8 bytes)
+
+struct LevelDesc {                                         // one pyramid level of the current geometry
+    int w, h, pitch;
+    int off;                                               // byte offset inside a frame's pyramid slab (levels >= 1)
+    int rzx, rzy;                                          // offsets into the resize tap tables
+    int cellBase, nCells;                                  // active FAST cells of this level in the cell table
+    int slotBase, slotCap;                                 // candidate slots: slotBase + cell*slotCap + k
+    int N, nIni, qtW, qtH;                                 // quadtree target, roots, extent (maxX-minX, maxY-minY)
+    float hX;
+    int selBase, selCap;                                   // quadtree output slots inside a frame
+    float sf;                                              // mvScaleFactor[level]
+    float patch;                                           // (float)(int)(31*sf)
+};
+
+struct CellInfo {                                          // one FAST cell (sub-image handed to cv::FAST)
+    short level, x0, y0, cw, ch, addx, addy, pad;
+    int slot;                                              // index of slot 0 of this cell within the frame
+    int cnt;                                               // index of the count word within the frame
+};
+
+struct TileInfo { short level, x0, y0, pad; };            // blur tiles
+
+struct Geom {                                              // kernel argument block (passed by value)
+    int nlevels, w0, h0;
+    int iniTh, minTh, lowTh;
+    int totalCells, totalSlots, totalSel, kpCap;
+    int nodeCap, sortCap;
+    size_t pyrFrameBytes;                                  // per-frame slab holding levels 1..L-1 (and a copy slot for 0)
+    LevelDesc lv[12];
+};
+
+__device__ __forceinline__ const u8* level_ptr(const Geom& g, const u8* const* l0, int l0pitch,
+                                               const u8* pyr, int frame, int level, int* pitch) {
+    if (level == 0) { *pitch = l0pitch; return l0[frame]; }
+    *pitch = g.lv[level].pitch;
+    return pyr + (size_t)frame * g.pyrFrameBytes + g.lv[level].off;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_resize: dst level from src level.  cv::resize INTER_LINEAR 8UC1:
+//   H[r][dx] = src[r][sx]*a0 + src[r][sx+1]*a1 ; dst = (((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2
+// block (64,4): each thread makes 4 consecutive dst pixels of one row and stores them as one dword.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(Geom g, const u8* const* l0, int l0pitch, u8* pyr, int level,
+                                                const RzTab* __restrict__ xt, const RzTab* __restrict__ yt) {
+    const LevelDesc& D = g.lv[level];
+    const LevelDesc& S = g.lv[level - 1];
+    const int frame = blockIdx.z;
+    const int dy = blockIdx.y * 4 + threadIdx.y;
+    const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (dy >= D.h || dx0 >= D.w) return;
+    int sp;
+    const u8* src = level_ptr(g, l0, l0pitch, pyr, frame, level - 1, &sp);
+    u8* dst = pyr + (size_t)frame * g.pyrFrameBytes + D.off;
+    const RzTab ty = yt[D.rzy + dy];
+    const int sy0 = min(max(ty.s, 0), S.h - 1), sy1 = min(max(ty.s + 1, 0), S.h - 1);
+    const u8* r0 = src + (size_t)sy0 * sp;
+    const u8* r1 = src + (size_t)sy1 * sp;
+    u32 packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int dx = dx0 + i;
+        if (dx < D.w) {
+            const RzTab tx = xt[D.rzx + dx];
+            const int sx1 = min(tx.s + 1, S.w - 1);
+            const int h0 = r0[tx.s] * tx.a0 + r0[sx1] * tx.a1;
+            const int h1 = r1[tx.s] * tx.a0 + r1[sx1] * tx.a1;
+            int v = (((ty.a0 * (h0 >> 4)) >> 16) + ((ty.a1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            v = min(max(v, 0), 255);
+            packed |= (u32)v << (8 * i);
+        }
+    }
+    u8* o = dst + (size_t)dy * D.pitch + dx0;
+    if (dx0 + 3 < D.pitch) *(u32*)o = packed;              // pitch is a multiple of 64: the padding absorbs the tail
+    else for (int i = 0; i < 4 && dx0 + i < D.w; ++i) o[i] = (u8)(packed >> (8 * i));
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST-9/16 score  S = max(A,B) - 1  (cv::cornerScore<16>), branch-free:
+//   B' = max_k min(ring[k..k+8]) ,  A' = min_k max(ring[k..k+8]) ;  A = v - A' , B = B' - v
+// 9-windows are built from 3-windows (min3/max3 map to v_min3/v_max3).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fast_score16(const u8* t, int p) {
+    const int v = t[0];
+    int r[16];
+    r[0] = t[3 * p];      r[1] = t[3 * p + 1];   r[2] = t[2 * p + 2];   r[3] = t[p + 3];
+    r[4] = t[3];          r[5] = t[-p + 3];      r[6] = t[-2 * p + 2];  r[7] = t[-3 * p + 1];
+    r[8] = t[-3 * p];     r[9] = t[-3 * p - 1];  r[10] = t[-2 * p - 2]; r[11] = t[-p - 3];
+    r[12] = t[-3];        r[13] = t[p - 3];      r[14] = t[2 * p - 2];  r[15] = t[3 * p - 1];
+    int lo3[16], hi3[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        lo3[k] = min(r[k], min(r[(k + 1) & 15], r[(k + 2) & 15]));
+        hi3[k] = max(r[k], max(r[(k + 1) & 15], r[(k + 2) & 15]));
+    }
+    int bmax = 0, amin = 255;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int lo9 = min(lo3[k], min(lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
+        const int hi9 = max(hi3[k], max(hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
+        bmax = max(bmax, lo9);
+        amin = min(amin, hi9);
+    }
+    return max(v - amin, bmax - v) - 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_fast: one workgroup per FAST cell (the sub-image the reference hands to cv::FAST).
+// LDS: the (cw x ch) byte tile and the score tile.  Non-max suppression never looks across the cell
+// (cv::FAST zero-fills outside the sub-image's 3-px frame), and the ini->min threshold fallback is
+// decided AFTER suppression (ORBextractor.cc:1118).  Because corner@t <=> S >= t, the set of 3x3 strict
+// local maxima is threshold independent: keypoints@ini = maxima with S >= ini, else maxima with S >= min.
+// Output: packed (x | y<<12 | S<<24) in row-major order into the cell's slot array + its count.
+// ------------------------------------------------------------------------------------------------
+#define ORBX_FAST_TILE 6400
+__global__ __launch_bounds__(256) void k_fast(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
+                                              const CellInfo* __restrict__ cells, u32* candCnt, u32* candEnt,
+                                              int* err) {
+    __shared__ u8 tile[ORBX_FAST_TILE];
+    __shared__ u8 sc[ORBX_FAST_TILE];
+    __shared__ int s_cntIni;
+    __shared__ int s_wave[4];
+    const CellInfo c = cells[blockIdx.x];
+    const int frame = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int cw = c.cw, ch = c.ch;
+    int sp;
+    const u8* src = level_ptr(g, l0, l0pitch, pyr, frame, c.level, &sp) + (size_t)c.y0 * sp + c.x0;
+    const int npx = cw * ch;
+    for (int i = tid; i < npx; i += 256) {
+        const int y = i / cw, x = i - y * cw;
+        tile[i] = src[(size_t)y * sp + x];
+        sc[i] = 0;
+    }
+    if (tid == 0) s_cntIni = 0;
+    __syncthreads();
+    const int vw = cw - 6, vh = ch - 6;                    // valid detection window (3-px frame excluded)
+    const int nv = vw > 0 && vh > 0 ? vw * vh : 0;
+    for (int i = tid; i < nv; i += 256) {
+        const int y = i / vw + 3, x = i - (y - 3) * vw + 3;
+        const int s = fast_score16(tile + y * cw + x, cw);
+        sc[y * cw + x] = (u8)(s >= g.lowTh ? s : 0);
+    }
+    __syncthreads();
+    // strict 3x3 maxima (frame of the tile holds zeros); flags kept in `tile` (no longer needed)
+    for (int i = tid; i < nv; i += 256) {
+        const int y = i / vw + 3, x = i - (y - 3) * vw + 3;
+        const u8* q = sc + y * cw + x;
+        const int s = q[0];
+        const bool keep = s > 0 && s > q[-1] && s > q[1] && s > q[-cw - 1] && s > q[-cw] && s > q[-cw + 1] &&
+                          s > q[cw - 1] && s > q[cw] && s > q[cw + 1];
+        tile[y * cw + x] = keep ? 1 : 0;
+        if (keep && s >= g.iniTh) atomicAdd(&s_cntIni, 1);
+    }
+    __syncthreads();
+    const int thr = s_cntIni > 0 ? g.iniTh : g.minTh;
+    const LevelDesc& L = g.lv[c.level];
+    u32* out = candEnt + (size_t)frame * g.totalSlots + c.slot;
+    const int lane = tid & 63, wv = tid >> 6;
+    int base = 0;
+    for (int i0 = 0; i0 < nv; i0 += 256) {                 // ordered (row-major) compaction, 256 px per step
+        const int i = i0 + tid;
+        bool f = false;
+        int x = 0, y = 0, s = 0;
+        if (i < nv) {
+            y = i / vw + 3; x = i - (y - 3) * vw + 3;
+            s = sc[y * cw + x];
+            f = tile[y * cw + x] && s >= thr;
+        }
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) s_wave[wv] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int k = 0; k < wv; ++k) off += s_wave[k];
+        const int tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (f) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < L.slotCap) out[pos] = (u32)(x + c.addx) | ((u32)(y + c.addy) << 12) | ((u32)s << 24);
+            else atomicExch(err, 1);
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) candCnt[(size_t)frame * g.totalCells + c.cnt] = (u32)base;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_quadtree: ORBextractor::DistributeOctTree for one (level, frame) per workgroup.
+// Keypoint-side work (quadrant histograms, re-labelling, per-node arg-max) is parallel over candidates;
+// the order-defining list surgery (push_front / erase / early break at N) is replayed by lane 0 on a
+// linked list held in LDS, which keeps the reference's output ORDER bit-exact.
+// Tie-break among equal-count nodes in the final phase: creation sequence (normative, see oracle).
+// ------------------------------------------------------------------------------------------------
+struct QtShared {                                         // carved from dynamic LDS, all arrays [nodeCap]
+    short4* rect; u32* cnt; u32* qc; u16* child; u16* nxt; u16* prv; u32* seq; u32* best; u8* split;
+    u16* freeStk; u16* cand; unsigned long long* sortKey; u16* order;
+};
+
+#define QT_NIL 0xFFFFu
+
+__device__ __forceinline__ int qt_quadrant(short4 r, int x, int y) {
+    const int hx = (r.z - r.x + 1) >> 1, hy = (r.w - r.y + 1) >> 1;      // ceil(d/2), d >= 0
+    const int mx = r.x + hx, my = r.y + hy;
+    return x < mx ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
+}
+
+__global__ __launch_bounds__(256) void k_quadtree(Geom g, const CellInfo* __restrict__ cells,
+                                                  const u32* __restrict__ candCnt, const u32* __restrict__ candEnt,
+                                                  u16* kpNode, u32* selOut, u32* selCnt, int* err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int level = blockIdx.x, frame = blockIdx.y;
+    const LevelDesc& L = g.lv[level];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cap = g.nodeCap;
+    QtShared S;
+    {
+        unsigned char* p = smem;
+        S.sortKey = (unsigned long long*)p; p += (size_t)g.sortCap * 8;
+        S.rect = (short4*)p; p += (size_t)cap * 8;
+        S.cnt = (u32*)p; p += (size_t)cap * 4;
+        S.qc = (u32*)p; p += (size_t)cap * 16;
+        S.seq = (u32*)p; p += (size_t)cap * 4;
+        S.best = (u32*)p; p += (size_t)cap * 4;
+        S.child = (u16*)p; p += (size_t)cap * 8;
+        S.nxt = (u16*)p; p += (size_t)cap * 2;
+        S.prv = (u16*)p; p += (size_t)cap * 2;
+        S.freeStk = (u16*)p; p += (size_t)cap * 2;
+        S.cand = (u16*)p; p += (size_t)cap * 2;
+        S.order = (u16*)p; p += (size_t)cap * 2;
+        S.split = (u8*)p; p += (size_t)cap;
+    }
+    __shared__ int s_head, s_size, s_state, s_nCand, s_nFree, s_seq, s_nPend;
+    const u32* cnts = candCnt + (size_t)frame * g.totalCells + L.cellBase;
+    const u32* ents = candEnt + (size_t)frame * g.totalSlots;
+    u16* kn = kpNode + (size_t)frame * g.totalSlots;
+
+    // ---- roots (ORBextractor.cc:695-763)
+    for (int i = tid; i < cap; i += 256) { S.cnt[i] = 0; S.split[i] = 0; }
+    __syncthreads();
+    for (int c = wv; c < L.nCells; c += 4) {
+        const int n = (int)cnts[c];
+        const int sb = cells[L.cellBase + c].slot;
+        for (int k = lane; k < n; k += 64) {
+            const u32 e = ents[sb + k];
+            const int root = (int)((float)(e & 0xFFF) / L.hX);
+            kn[sb + k] = (u16)root;
+            atomicAdd(&S.cnt[root], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int head = QT_NIL, tail = QT_NIL, size = 0;
+        for (int i = 0; i < L.nIni; ++i) {
+            S.rect[i] = make_short4((short)(int)(L.hX * (float)i), 0, (short)(int)(L.hX * (float)(i + 1)), (short)L.qtH);
+            S.seq[i] = i;
+            if (S.cnt[i] == 0) continue;                       // empty roots are erased
+            S.nxt[i] = QT_NIL; S.prv[i] = (u16)tail;
+            if (tail != QT_NIL) S.nxt[tail] = (u16)i; else head = i;
+            tail = i; ++size;
+        }
+        int nf = 0;
+        for (int i = cap - 1; i >= L.nIni; --i) S.freeStk[nf++] = (u16)i;
+        s_head = head; s_size = size; s_nFree = nf; s_seq = L.nIni; s_state = 0; s_nCand = 0; s_nPend = 0;
+    }
+    __syncthreads();
+
+    // ---- refinement passes
+    for (int iter = 0;; ++iter) {
+        const int state = s_state;                          // uniform: lane 0 only rewrites it after the next barrier
+        if (state == 2) break;
+        if (iter > 8192) { if (tid == 0) atomicExch(err, 4); break; }
+        // (1) quadrant histograms of every splittable node
+        for (int i = tid; i < cap * 4; i += 256) S.qc[i] = 0;
+        __syncthreads();
+        for (int c = wv; c < L.nCells; c += 4) {
+            const int n = (int)cnts[c];
+            const int sb = cells[L.cellBase + c].slot;
+            for (int k = lane; k < n; k += 64) {
+                const int nd = kn[sb + k];
+                if (S.cnt[nd] > 1) {
+                    const u32 e = ents[sb + k];
+                    atomicAdd(&S.qc[nd * 4 + qt_quadrant(S.rect[nd], e & 0xFFF, (e >> 12) & 0xFFF)], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        // (1b) final phase: order the candidates by (count, creation seq) ascending -- bitonic sort in LDS
+        if (state == 1) {
+            const int nc = s_nCand;
+            int n2 = 1;
+            while (n2 < nc) n2 <<= 1;
+            for (int i = tid; i < n2; i += 256) {
+                unsigned long long key = ~0ull;
+                if (i < nc) {
+                    const int id = S.cand[i];
+                    key = ((unsigned long long)S.cnt[id] << 40) | ((unsigned long long)S.seq[id] << 16) | (unsigned)id;
+                }
+                S.sortKey[i] = key;
+            }
+            __syncthreads();
+            for (int k = 2; k <= n2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < n2; i += 256) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const unsigned long long a = S.sortKey[i], b = S.sortKey[ixj];
+                            const bool up = (i & k) == 0;
+                            if ((a > b) == up) { S.sortKey[i] = b; S.sortKey[ixj] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+        }
+        // (2) list surgery by lane 0
+        if (tid == 0) {
+            int head = s_head, size = s_size, nf = s_nFree, seq = s_seq, npend = 0;
+            const int prevSize = size;
+            const int N = L.N;
+            int nNew = 0, nToExpand = 0;
+            bool overflow = false;
+            auto split_node = [&](int it) {
+                const short4 r = S.rect[it];
+                const int hx = (r.z - r.x + 1) >> 1, hy = (r.w - r.y + 1) >> 1;
+                const int mx = r.x + hx, my = r.y + hy;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32 qn = S.qc[it * 4 + q];
+                    int id = QT_NIL;
+                    if (qn > 0) {
+                        if (nf == 0) { overflow = true; }
+                        else {
+                            id = S.freeStk[--nf];
+                            S.rect[id] = make_short4((short)((q & 1) ? mx : r.x), (short)((q & 2) ? my : r.y),
+                                                     (short)((q & 1) ? r.z : mx), (short)((q & 2) ? r.w : my));
+                            S.cnt[id] = qn; S.seq[id] = seq++; S.split[id] = 0;
+                            S.prv[id] = QT_NIL; S.nxt[id] = (u16)head;          // push_front
+                            if (head != QT_NIL) S.prv[head] = (u16)id;
+                            head = id; ++size;
+                            if (qn > 1) { ++nToExpand; S.order[nNew++] = (u16)id; }
+                        }
+                    }
+                    S.child[it * 4 + q] = (u16)id;
+                }
+                const int p = S.prv[it], n = S.nxt[it];                         // erase(it)
+                if (p != QT_NIL) S.nxt[p] = (u16)n; else head = n;
+                if (n != QT_NIL) S.prv[n] = (u16)p;
+                --size;
+                S.split[it] = 1;
+                S.cand[cap - 1 - npend] = (u16)it; ++npend;                     // pending free (tail of cand[])
+            };
+            bool finish = false;
+            if (state == 0) {                                                    // ORBextractor.cc:779-895
+                int it = head;
+                // nodes pushed to the front are not revisited in this pass
+                while (it != QT_NIL) {
+                    const int nx = S.nxt[it];
+                    if (S.cnt[it] > 1) split_node(it);
+                    it = nx;
+                }
+                if (size >= N || size == prevSize) finish = true;
+                else if (size + nToExpand * 3 > N) s_state = 1;
+            } else {                                                             // ORBextractor.cc:912-992
+                const int nc = s_nCand;
+                for (int j = nc - 1; j >= 0; --j) {
+                    split_node((int)(S.sortKey[j] & 0xFFFF));
+                    if (size >= N) break;
+                }
+                if (size >= N || size == prevSize) finish = true;
+            }
+            if (overflow) { atomicExch(err, 2); finish = true; }
+            // candidates of the next round = the children created now, in creation order
+            for (int i = 0; i < nNew; ++i) S.cand[i] = S.order[i];
+            s_nCand = nNew; s_nPend = npend;
+            s_head = head; s_size = size; s_nFree = nf; s_seq = seq;
+            if (finish) s_state = 2;
+        }
+        __syncthreads();
+        // (3) move the keypoints of split nodes to their children
+        for (int c = wv; c < L.nCells; c += 4) {
+            const int n = (int)cnts[c];
+            const int sb = cells[L.cellBase + c].slot;
+            for (int k = lane; k < n; k += 64) {
+                const int nd = kn[sb + k];
+                if (S.split[nd]) {
+                    const u32 e = ents[sb + k];
+                    kn[sb + k] = S.child[nd * 4 + qt_quadrant(S.rect[nd], e & 0xFFF, (e >> 12) & 0xFFF)];
+                }
+            }
+        }
+        __syncthreads();
+        // (4) recycle the erased parents
+        if (tid == 0) {
+            int nf = s_nFree;
+            for (int i = 0; i < s_nPend; ++i) {
+                const int it = S.cand[cap - 1 - i];
+                S.split[it] = 0; S.cnt[it] = 0;
+                S.freeStk[nf++] = (u16)it;
+            }
+            s_nFree = nf; s_nPend = 0;
+        }
+        __syncthreads();
+    }
+    // ---- one keypoint per node: first maximum of `response` in candidate order (ORBextractor.cc:1005-1030)
+    for (int i = tid; i < cap; i += 256) S.best[i] = 0;
+    __syncthreads();
+    for (int c = wv; c < L.nCells; c += 4) {
+        const int n = (int)cnts[c];
+        const int sb = cells[L.cellBase + c].slot;
+        for (int k = lane; k < n; k += 64) {
+            const u32 e = ents[sb + k];
+            const u32 rel = (u32)(sb + k - L.slotBase);                          // canonical order inside the level
+            atomicMax(&S.best[kn[sb + k]], ((e >> 24) << 24) | (0xFFFFFFu - rel));
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int pos = 0;
+        for (int it = s_head; it != QT_NIL; it = S.nxt[it]) S.order[pos++] = (u16)it;
+        s_size = pos;
+    }
+    __syncthreads();
+    const int nsel = s_size;
+    u32* so = selOut + (size_t)frame * g.totalSel + L.selBase;
+    for (int i = tid; i < nsel; i += 256) {
+        if (i < L.selCap) {
+            const u32 key = S.best[S.order[i]];
+            so[i] = ents[L.slotBase + (0xFFFFFFu - (key & 0xFFFFFFu))];
+        } else atomicExch(err, 3);
+    }
+    if (tid == 0) selCnt[frame * g.nlevels + level] = (u32)min(nsel, L.selCap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_slots: one workgroup per frame.  Walks the levels in order, fixes up coordinates/octave/size
+// (ORBextractor.cc:1161-1176), scales to level-0 coordinates and assigns the output row:
+// lapping keypoints fill the output from the back, the rest from the front (:1633-1655).
+// ------------------------------------------------------------------------------------------------
+struct KpWork { short level, x, y, pad; int slot; };       // 12 bytes
+
+struct KpOut { float x, y, size, angle, response; int octave, class_id; };
+
+__global__ __launch_bounds__(256) void k_slots(Geom g, const u32* __restrict__ selOut, const u32* __restrict__ selCnt,
+                                               const int* __restrict__ lap01, KpOut* kps, KpWork* work,
+                                               int* nOut, int* monoOut) {
+    __shared__ int s_wave[4];
+    __shared__ int s_lvOff[13];
+    const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) {
+        int o = 0;
+        for (int l = 0; l < g.nlevels; ++l) { s_lvOff[l] = o; o += (int)selCnt[frame * g.nlevels + l]; }
+        s_lvOff[g.nlevels] = o;
+    }
+    __syncthreads();
+    const int n = s_lvOff[g.nlevels];
+    const int lap0 = lap01 ? lap01[2 * frame] : 0, lap1 = lap01 ? lap01[2 * frame + 1] : 0;
+    const u32* so = selOut + (size_t)frame * g.totalSel;
+    KpOut* ko = kps + (size_t)frame * g.kpCap;
+    KpWork* wo = work + (size_t)frame * g.kpCap;
+    int lapBefore = 0;                                      // lapping keypoints before this chunk
+    for (int p0 = 0; p0 < n; p0 += 256) {
+        const int p = p0 + tid;
+        bool isLap = false;
+        int level = 0, x = 0, y = 0, r = 0;
+        float fx = 0, fy = 0;
+        if (p < n) {
+            while (p >= s_lvOff[level + 1]) ++level;
+            const u32 e = so[g.lv[level].selBase + (p - s_lvOff[level])];
+            x = (int)(e & 0xFFF) + 16; y = (int)((e >> 12) & 0xFFF) + 16; r = (int)(e >> 24);
+            fx = (float)x; fy = (float)y;
+            if (level != 0) { fx *= g.lv[level].sf; fy *= g.lv[level].sf; }
+            isLap = fx >= (float)lap0 && fx <= (float)lap1;
+        }
+        const unsigned long long m = __ballot(isLap);
+        if (lane == 0) s_wave[wv] = __popcll(m);
+        __syncthreads();
+        int before = lapBefore;
+        for (int k = 0; k < wv; ++k) before += s_wave[k];
+        before += __popcll(m & ((1ull << lane) - 1ull));
+        const int tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (p < n) {
+            const int slot = isLap ? (n - 1 - before) : (p - before);
+            KpOut k;
+            k.x = fx; k.y = fy; k.size = g.lv[level].patch; k.angle = -1.f; k.response = (float)r;
+            k.octave = level; k.class_id = -1;
+            ko[slot] = k;
+            KpWork w; w.level = (short)level; w.x = (short)x; w.y = (short)y; w.pad = 0; w.slot = slot;
+            wo[p] = w;
+        }
+        lapBefore += tot;
+        __syncthreads();
+    }
+    if (tid == 0) { nOut[frame] = n; monoOut[frame] = n - lapBefore; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_blur: cv::GaussianBlur 7x7 sigma 2 reflect-101, taps [18,34,48,56,48,34,18]/256:
+// horizontal pass exact in Q8.8, vertical pass to Q16.16, one rounding (+32768)>>16.
+// Tile 64x32 outputs per workgroup, source window (70x38) staged in LDS.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+
+#define BL_TW 64
+#define BL_TH 32
+__global__ __launch_bounds__(256) void k_blur(Geom g, const u8* const* l0, int l0pitch, const u8* pyr, u8* blr,
+                                              const TileInfo* __restrict__ tiles) {
+    __shared__ u8 src[(BL_TH + 6) * (BL_TW + 8)];
+    __shared__ u16 hb[(BL_TH + 6) * BL_TW];
+    const TileInfo t = tiles[blockIdx.x];
+    const int frame = blockIdx.y, tid = threadIdx.x;
+    const LevelDesc& L = g.lv[t.level];
+    int sp;
+    const u8* im = level_ptr(g, l0, l0pitch, pyr, frame, t.level, &sp);
+    const int SW = BL_TW + 8;
+    for (int i = tid; i < (BL_TH + 6) * (BL_TW + 6); i += 256) {
+        const int yy = i / (BL_TW + 6), xx = i - yy * (BL_TW + 6);
+        const int sy = reflect101(t.y0 + yy - 3, L.h), sx = reflect101(t.x0 + xx - 3, L.w);
+        src[yy * SW + xx] = im[(size_t)sy * sp + sx];
+    }
+    __syncthreads();
+    for (int i = tid; i < (BL_TH + 6) * BL_TW; i += 256) {
+        const int yy = i / BL_TW, xx = i - yy * BL_TW;
+        const u8* s = src + yy * SW + xx;
+        hb[i] = (u16)(18 * (s[0] + s[6]) + 34 * (s[1] + s[5]) + 48 * (s[2] + s[4]) + 56 * s[3]);
+    }
+    __syncthreads();
+    u8* dst = blr + (size_t)frame * g.pyrFrameBytes + L.off;
+    for (int i = tid; i < BL_TH * BL_TW; i += 256) {
+        const int yy = i / BL_TW, xx = i - yy * BL_TW;
+        const int ox = t.x0 + xx, oy = t.y0 + yy;
+        if (ox < L.w && oy < L.h) {
+            const u16* h = hb + yy * BL_TW + xx;
+            const u32 acc = 18u * (h[0] + h[6 * BL_TW]) + 34u * (h[BL_TW] + h[5 * BL_TW]) +
+                            48u * (h[2 * BL_TW] + h[4 * BL_TW]) + 56u * h[3 * BL_TW];
+            dst[(size_t)oy * L.pitch + ox] = (u8)((acc + 32768u) >> 16);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_orient_desc: one wavefront per keypoint.
+//  * IC_Angle (ORBextractor.cc:91-138): integer moments over the 749-pixel disc on the UN-blurred level,
+//    wave-reduced with __shfl_xor, then cv::fastAtan2 in float32 without contraction.
+//  * computeOrbDescriptor (:150-203): lane l evaluates pairs 4l..4l+3 on the BLURRED level,
+//    nibbles are merged across 8-lane groups with shuffles; lanes 0,8,..,56 store one dword each.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float s = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s,
+                p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps); c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps); c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+struct Umax { int v[16]; };
+
+__global__ __launch_bounds__(256) void k_orient_desc(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
+                                                     const u8* blr, const KpWork* __restrict__ work,
+                                                     const int* __restrict__ nOut, KpOut* kps, u8* desc,
+                                                     const int8_t* __restrict__ pattern, Umax um) {
+    const int frame = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= nOut[frame]) return;
+    const KpWork w = work[(size_t)frame * g.kpCap + p];
+    int sp;
+    const u8* im = level_ptr(g, l0, l0pitch, pyr, frame, w.level, &sp);
+    const u8* c = im + (size_t)w.y * sp + w.x;
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < 31 * 32; i += 64) {
+        const int v = (i >> 5) - 15, u = (i & 31) - 15;
+        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+        if (au <= um.v[av]) {
+            const int val = c[v * sp + u];
+            m10 += u * val; m01 += v * val;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    // descriptor
+    const LevelDesc& L = g.lv[w.level];
+    const u8* bc = blr + (size_t)frame * g.pyrFrameBytes + L.off + (size_t)w.y * L.pitch + w.x;
+    const int bp = L.pitch;
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float ar = angle * factorPI;
+    const float a = (float)cos((double)ar), b = (float)sin((double)ar);
+    const int4 raw = *(const int4*)(pattern + 16 * lane);
+    const int wds[4] = {raw.x, raw.y, raw.z, raw.w};
+    u32 nib = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float x0 = (float)(int8_t)(wds[k] & 0xFF), y0 = (float)(int8_t)((wds[k] >> 8) & 0xFF);
+        const float x1 = (float)(int8_t)((wds[k] >> 16) & 0xFF), y1 = (float)(int8_t)((wds[k] >> 24) & 0xFF);
+        const int t0 = bc[__float2int_rn(x0 * b + y0 * a) * bp + __float2int_rn(x0 * a - y0 * b)];
+        const int t1 = bc[__float2int_rn(x1 * b + y1 * a) * bp + __float2int_rn(x1 * a - y1 * b)];
+        nib |= (u32)(t0 < t1) << k;
+    }
+    u32 word = nib << (4 * (lane & 7));
+    word |= __shfl_xor(word, 1);
+    word |= __shfl_xor(word, 2);
+    word |= __shfl_xor(word, 4);
+    const size_t row = (size_t)frame * g.kpCap + w.slot;
+    if ((lane & 7) == 0) ((u32*)(desc + row * 32))[lane >> 3] = word;
+    if (lane == 0) kps[row].angle = angle;
+}
+
+}  // namespace orbxk
