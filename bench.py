@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- ORB extract+match frames/sec @752x480, 1000 features (BASELINE.json metric).
+
+One step = one pass of the hot path over one batch of B synthetic frames already resident in HBM:
+  extraction of every frame (8-level pyramid, FAST, quadtree, orientation, blur, rBRIEF) followed by the
+  Hamming match of each frame's descriptors against the previous frame's (dense 2-NN, orbm_knn2).
+N GPUs = N processes (torch.distributed / RCCL), each with its own B frames ("weak" scaling); the only
+collective is the all_gather of per-frame keypoint counts after the timed steps' last batch.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  "roofline"     -- pyramid+FAST pass: algorithmic bytes / HIP-event time of those launches
+  "cpu_baseline" -- the CPU oracle (a port, 1 thread) on a bounded sample of the same frames.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0       # MI355X spec (MI355X_MICROARCH.md): 8.0 TB/s; 6.29 TB/s measured copy peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step")
+    ap.add_argument("--width", type=int, default=752)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic frames generated per rank")
+    ap.add_argument("--cpu-sample", type=int, default=96, help="frames timed through the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch                       # plumbing: device sync + torch.distributed (RCCL); imported BEFORE the
+    import torch.distributed as dist   # HIP library so both share one libamdhip64 runtime
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module("orb-slam3_amd")
+    synth = importlib.import_module("orb-slam3_amd.synth")
+    L = pkg.lib()
+
+    W, H, B = args.width, args.height, args.batch
+    ex = pkg.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local_rank, max_size=(W, H), max_batch=B)
+    mt = pkg.ORBmatcher(0.7, device=local_rank)
+    cap = ex.cap
+
+    # ---- inputs resident in HBM before the timed region
+    stride = (W + 63) // 64 * 64
+    host_imgs = [synth.gen_image(W, H, 1000 * rank + 1 + i) for i in range(min(args.distinct, B))]
+    dev = pkg.DeviceBuffer(stride * H * B)
+    padded = np.zeros((H, stride), np.uint8)
+    for i in range(B):
+        padded[:, :W] = host_imgs[i % len(host_imgs)]
+        dev.upload(padded, offset=i * stride * H)
+    ptrs = (C.c_void_p * B)(*[dev.ptr + i * stride * H for i in range(B)])
+    lap = np.tile(np.array([0, 1000], np.int32), B)       # monocular call: vLapping = {0,1000} (Frame.cc:361)
+
+    res = ex.result_device()
+    idx2 = pkg.DeviceBuffer(B * cap * 2 * 4)
+    dist2 = pkg.DeviceBuffer(B * cap * 2 * 4)
+
+    def step():
+        ex.enqueue_device(ptrs, W, H, stride, lap)
+        # match frame i (query) against frame i-1 (train); frame 0 against frame B-1 of the same batch.
+        # Both kernels run on their own streams: order them with a sync-free event-less handoff by syncing
+        # the extractor stream first (cheap vs the step; keeps the result buffers coherent).
+        ex.sync()
+        rc = L.orbm_knn2_batch_async(mt.h, res["desc"] + cap * 32, cap, res["counts"] + 4, res["desc"], cap,
+                                     res["counts"], B - 1, cap, idx2.ptr + cap * 8, dist2.ptr + cap * 8)
+        assert rc == 0, rc
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    mt.sync()
+    t_pyr, t_fast, t_all = [], [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        tm = ex.timings()                                  # HIP events on the extractor's own stream
+        t_pyr.append(tm["pyramid"]); t_fast.append(tm["fast"]); t_all.append(tm)
+    mt.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+
+    counts = ex.result_device()
+    n_host = dev_counts = None
+    cnt = pkg.DeviceBuffer(4 * B)                          # keypoint counts of the last batch
+    L.orbx_memcpy_d2h  # (bound)
+    n_host = np.zeros(B, np.int32)
+    L.orbx_memcpy_d2h(n_host.ctypes.data_as(C.c_void_p), counts["counts"], 4 * B)
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    total_kp = torch.tensor([int(n_host.sum())], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros_like(total_kp) for _ in range(world)]
+        dist.all_gather(gathered, total_kp)                # RCCL: the path's only exchange (keypoint counts)
+        total_kp = torch.stack(gathered).sum()
+    dt = float(tmax.item())
+
+    if rank == 0:
+        frames = B * args.steps * world
+        alg, fused = ex.algorithmic_bytes()
+        pf_ms = float(np.mean(t_pyr) + np.mean(t_fast))
+        achieved = alg * B / (pf_ms * 1e-3) / 1e9
+        stage = {k: float(np.mean([t[k] for t in t_all])) for k in t_all[0]}
+        stage["knn2"] = mt.timing_ms()
+        out = {
+            "metric": "ORB extract+match frames/sec @752x480, 1000 feat",
+            "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: %dx%d grayscale, %d features, 8 levels, scale 1.2, FAST 20/7; "
+                                   "batch of %d frames/GPU/step resident in HBM; extract + dense 2-NN Hamming "
+                                   "match against the previous frame" % (W, H, args.nfeatures, B),
+                       "frames_per_step_per_gpu": B, "keypoints_last_batch": int(total_kp.item())},
+            "roofline": {"bound": "hbm", "kernel": "pyramid+FAST pass (k_resize x7 + k_fast)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_frame": alg, "fused_lower_bound_per_frame": fused,
+                         "launch_ms": pf_ms},
+            "stage_ms_per_step": stage,
+        }
+        if world == 1 and args.cpu_sample > 0:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import orbref                                   # the checker, timed as the CPU baseline ("port")
+            ref = orbref.Extractor(args.nfeatures, 1.2, 8, 20, 7)
+            ns = args.cpu_sample
+            prev = None
+            tc = time.perf_counter()
+            for i in range(ns):
+                n, kps, desc, mono = ref(host_imgs[i % len(host_imgs)], (0, 1000))
+                if prev is not None:
+                    orbref.knn2(desc, prev)
+                prev = desc
+            tcpu = time.perf_counter() - tc
+            out["cpu_baseline"] = {"value": ns / tcpu, "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": "%d frames of the same synthetic stream through oracle/liborbref.so "
+                                             "(extract + 2-NN match vs previous frame), 1 thread" % ns,
+                                   "stage_ms_per_frame": {k: v / ns for k, v in ref.stage_ms().items()}}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,7 +30,13 @@ def gen_image(w, h, seed, kind="textured"):
         amp *= 0.6
     img = (img - img.mean()) / (img.std() + 1e-9)
     if kind == "lowcontrast":
-        img = 128 + 4.0 * img
+        # faint structure: most FAST cells hold corners only in the [minTh, iniTh) band -> exercises the
+        # per-cell ini->min threshold fallback (ORBextractor.cc:1118-1125)
+        img = 128 + 6.0 * img
+        for _ in range(max(1, w * h // 900)):
+            rw = int(rng.integers(3, 30)); rh = int(rng.integers(3, 30))
+            x = int(rng.integers(0, max(1, w - rw))); y = int(rng.integers(0, max(1, h - rh)))
+            img[y:y + rh, x:x + rw] += float(rng.integers(9, 17)) * (1 if rng.random() < 0.5 else -1)
         img += rng.normal(0, 0.7, img.shape)
         return np.clip(np.rint(img), 0, 255).astype(np.uint8)
     img = 110 + 45 * img

@@ -1,0 +1,96 @@
+"""GPU parity: the HIP extractor through the C ABI vs the CPU oracle, bit-exact (integer/byte/index work;
+the three float fields -- angle, scaled x/y -- are compared bit-for-bit too)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (w, h, nfeatures, seed, lapping, kind)      BASELINE.json configs C1/C2, C3, C4 + degenerate frames
+    (752, 480, 1000, 1, (0, 1000), "textured"),
+    (752, 480, 1200, 100, (0, 0), "textured"),
+    (512, 512, 1500, 200, (0, 511), "textured"),
+    (752, 480, 1000, 9, (0, 0), "lowcontrast"),
+    (752, 480, 1000, 0, (0, 0), "constant"),
+    (640, 480, 1000, 5, (100, 400), "textured"),
+    (421, 307, 500, 6, (0, 0), "textured"),          # odd sizes, ragged last cells
+]
+
+
+def _check(pkg, oracle, synth, w, h, nf, seed, lap, kind, stages=True):
+    img = synth.gen_image(w, h, seed, kind)
+    ref = oracle.Extractor(nf)
+    n_ref, kps_ref, desc_ref, mono_ref = ref(img, lap)
+    ex = pkg.ORBextractor(nf, max_size=(w, h), max_batch=1)
+    mono, kps, desc = ex(img, lap)
+    if stages:
+        for l in range(8):
+            assert np.array_equal(ex.level_image(l), ref.level_image(l)), "pyramid level %d" % l
+            assert np.array_equal(ex.level_candidates(l), ref.level_candidates(l)), "FAST candidates level %d" % l
+            assert np.array_equal(ex.level_selected(l), ref.level_keypoints(l)[0]), "quadtree level %d" % l
+            bl = ref.level_image(l, blurred=True)
+            if bl is not None:
+                assert np.array_equal(ex.level_image(l, blurred=True), bl), "blur level %d" % l
+    assert len(kps) == n_ref and mono == mono_ref
+    assert kps.tobytes() == kps_ref.tobytes()                   # all 7 fields, bit for bit, same order
+    assert np.array_equal(desc, desc_ref)
+    ex.close()
+    return n_ref
+
+
+@pytest.mark.parametrize("w,h,nf,seed,lap,kind", CASES)
+def test_extract_bit_exact(pkg, oracle, synth, w, h, nf, seed, lap, kind):
+    n = _check(pkg, oracle, synth, w, h, nf, seed, lap, kind)
+    if kind == "textured":
+        assert n >= nf // 2
+
+
+def test_extract_full_hd_4000(pkg, oracle, synth):
+    # BASELINE config C5 at full size
+    assert _check(pkg, oracle, synth, 1920, 1080, 4000, 300, (0, 0), "textured", stages=False) >= 3900
+
+
+def test_mono_init_extractor_5x(pkg, oracle, synth):
+    # Tracking.cc:1113: the monocular-initialisation extractor asks for 5*nFeatures
+    _check(pkg, oracle, synth, 752, 480, 5000, 12, (0, 1000), "textured", stages=False)
+
+
+def test_batch_equals_single(pkg, oracle, synth):
+    imgs = [synth.gen_image(752, 480, 40 + i) for i in range(6)] + [synth.gen_image(752, 480, 0, "constant")]
+    ex = pkg.ORBextractor(1000, max_size=(752, 480), max_batch=len(imgs))
+    laps = [(0, 1000)] * 3 + [(0, 0)] * 4
+    res = ex.extract_batch(imgs, laps)
+    ref = oracle.Extractor(1000)
+    for img, lap, (mono, kps, desc) in zip(imgs, laps, res):
+        n_ref, kps_ref, desc_ref, mono_ref = ref(img, lap)
+        assert len(kps) == n_ref and mono == mono_ref
+        assert kps.tobytes() == kps_ref.tobytes() and np.array_equal(desc, desc_ref)
+
+
+def test_idempotent_and_geometry_switch(pkg, synth):
+    # the extractor is stateful (pyramid overwritten per call): same input twice -> same output; a new image
+    # size rebuilds the geometry
+    ex = pkg.ORBextractor(1000, max_size=(752, 480), max_batch=1)
+    a = synth.gen_image(752, 480, 3); b = synth.gen_image(640, 400, 3)
+    r1 = ex(a); r2 = ex(b); r3 = ex(a)
+    assert r1[0] == r3[0] and r1[1].tobytes() == r3[1].tobytes() and np.array_equal(r1[2], r3[2])
+    assert len(r2[1]) > 0
+
+
+def test_error_paths(pkg, synth):
+    ex = pkg.ORBextractor(1000, max_size=(752, 480), max_batch=1)
+    assert ex(np.zeros((0, 0), np.uint8))[0] == -1                # empty image: reference returns -1
+    with pytest.raises(pkg.OrbError):
+        ex(synth.gen_image(1024, 768, 1))                         # larger than configured maximum
+    with pytest.raises(pkg.OrbError):
+        ex(synth.gen_image(120, 100, 1))                          # top level narrower than one FAST cell
+    with pytest.raises(pkg.OrbError):
+        pkg.ORBextractor(1000, scale_factor=1.0)
+
+
+def test_getters_match_oracle_tables(pkg, oracle):
+    ex = pkg.ORBextractor(1000, max_size=(752, 480))
+    t = oracle.Extractor(1000).tables()
+    assert np.array_equal(ex.GetScaleFactors(), t["sf"]) and np.array_equal(ex.GetInverseScaleFactors(), t["inv_sf"])
+    assert np.array_equal(ex.GetScaleSigmaSquares(), t["sig2"]) and np.array_equal(ex.GetInverseScaleSigmaSquares(), t["inv_sig2"])
+    assert np.array_equal(ex.features_per_level(), t["nfeat"]) and ex.GetLevels() == 8
