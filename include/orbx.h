@@ -89,6 +89,8 @@ int orbx_last_timings(orbx_t*, float* ms7);
 /* algorithmic bytes of the pyramid+FAST pass for one frame of the current geometry */
 int64_t orbx_algorithmic_bytes(const orbx_t*, int64_t* fused_lower_bound);
 void* orbx_stream(const orbx_t*);     /* hipStream_t the kernels are launched on */
+/* diagnostic builds only (-DORBX_STAMPS): accumulated per-phase cycle stamps of the FAST kernel; zeros otherwise */
+int orbx_debug_stamps(orbx_t*, unsigned long long* out, int n);
 
 /* plain device-memory helpers so callers need no HIP bindings of their own */
 void* orbx_dev_alloc(size_t bytes);

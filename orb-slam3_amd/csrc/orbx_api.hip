@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -40,21 +41,36 @@ struct orbx {
     int curW = 0, curH = 0;
     Geom g;
     std::vector<CellInfo> cells;
-    std::vector<TileInfo> tiles;
+    std::vector<BlurTask> tiles;
+    BlurSel blurSel;
+    std::vector<StripInfo> strips;
+    StripInfo* dStrips = nullptr; size_t capStrips = 0;
+    bool fastV1 = false;
+    int f3Tile = 0, f3Qcap = 0;
+    size_t f3Lds = 0;
     std::vector<RzTab> xt, yt;
+    std::vector<RzX4> x4;
+    std::vector<RzTask> rzTasks[12];
+    RzX4* dX4 = nullptr; RzTask* dRzTasks = nullptr; size_t capX4 = 0, capRzTasks = 0;
+    int rzTaskOff[12] = {}; bool rzStream[12] = {};
     int64_t algBytes = 0, fusedBytes = 0;
-    size_t qtLds = 0;
+    size_t qtLds = 0, qt2Lds = 0;
+    int qt2Cap = 0, qt2Sort = 0;
+    bool qtV1 = false;
     // device
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     u8 *dPyr = nullptr, *dBlur = nullptr, *dL0 = nullptr;
     const u8** dL0Ptr = nullptr;
-    CellInfo* dCells = nullptr; TileInfo* dTiles = nullptr; RzTab *dXt = nullptr, *dYt = nullptr;
+    CellInfo* dCells = nullptr; BlurTask* dTiles = nullptr; RzTab *dXt = nullptr, *dYt = nullptr;
     u32 *dCandCnt = nullptr, *dCandEnt = nullptr, *dSel = nullptr, *dSelCnt = nullptr;
     u16* dKpNode = nullptr;
+    u32* dDense = nullptr;
+    int maxCells = 0;
     KpOut* dKps = nullptr; u8* dDesc = nullptr; KpWork* dWork = nullptr;
     int *dN = nullptr, *dMono = nullptr, *dLap = nullptr, *dErr = nullptr;
     int8_t* dPattern = nullptr;
+    unsigned long long* dStamps = nullptr;
     size_t capL0 = 0, capPyr = 0, capCells = 0, capTiles = 0, capXt = 0, capYt = 0, capCandCnt = 0, capCandEnt = 0, capSel = 0;
     int lastBatch = 0;
     int l0pitch = 0;
@@ -80,7 +96,7 @@ static int build_geometry(orbx* o, int w, int h) {
     memset(&g, 0, sizeof g);
     const int L = o->nlevels;
     g.nlevels = L; g.w0 = w; g.h0 = h; g.iniTh = o->iniTh; g.minTh = o->minTh; g.lowTh = std::min(o->iniTh, o->minTh);
-    o->cells.clear(); o->tiles.clear(); o->xt.clear(); o->yt.clear();
+    o->cells.clear(); o->tiles.clear(); o->strips.clear(); o->f3Tile = 0; o->f3Qcap = 0; o->xt.clear(); o->yt.clear(); o->x4.clear(); for (auto& v : o->rzTasks) v.clear();
     size_t off = 0;
     int totalSlots = 0, totalSel = 0, maxN = 0;
     int64_t sumAll = 0, sumSrc = 0, sumDst = 0;
@@ -130,6 +146,35 @@ static int build_geometry(orbx* o, int w, int h) {
             }
         }
         D.nCells = (int)o->cells.size() - D.cellBase;
+        // strips for k_fast3: runs of <= 8 cells of one cell-row (one wavefront per cell); the tile pitch is a
+        // multiple of 16 bytes (<= 512) and starts >= 4 bytes left of the strip at a 16-byte aligned column
+        for (int ci = D.cellBase; ci < (int)o->cells.size();) {
+            const CellInfo& f = o->cells[ci];
+            const int Hs = f.ch;
+            if (Hs > 127) { set_err("FAST cell of %d rows exceeds the strip kernel's 127", Hs); return ORBX_E_UNSUPPORTED; }
+            const int xal = (f.x0 - 4) & ~15;
+            int n = 0, needed = 0;
+            while (ci + n < (int)o->cells.size() && n < 8) {
+                const CellInfo& c = o->cells[ci + n];
+                if (c.y0 != f.y0) break;
+                const int nd = c.x0 + c.cw - 3 - xal + 8;
+                if (nd > 512) break;
+                needed = nd; ++n;
+            }
+            if (n == 0) { set_err("FAST cell %dx%d does not fit the strip tile", f.cw, f.ch); return ORBX_E_UNSUPPORTED; }
+            const CellInfo& last = o->cells[ci + n - 1];
+            StripInfo st;
+            st.level = (short)l; st.ncell = (short)n; st.x0 = f.x0; st.y0 = f.y0;
+            st.w = (short)(last.x0 + last.cw - f.x0); st.h = (short)Hs; st.xal = (short)xal;
+            st.lp = (short)align_up(needed, 16); st.cell0 = ci;
+            o->f3Tile = std::max(o->f3Tile, (int)st.lp * Hs);
+            for (int k = 0; k < n; ++k) {
+                const CellInfo& c = o->cells[ci + k];
+                o->f3Qcap = std::max(o->f3Qcap, align_up(std::max(0, c.cw - 6) * std::max(0, c.ch - 6), 64));
+            }
+            o->strips.push_back(st);
+            ci += n;
+        }
         if (totalSlots - D.slotBase >= (1 << 24)) { set_err("level %d has too many candidate slots", l); return ORBX_E_UNSUPPORTED; }
         // quadtree roots (ORBextractor.cc:695-699)
         D.qtW = maxBX - minB; D.qtH = maxBY - minB;
@@ -140,9 +185,15 @@ static int build_geometry(orbx* o, int w, int h) {
         D.selCap = std::max(D.N + 3, 4 * D.nIni) + 1;
         totalSel += D.selCap;
         maxN = std::max(maxN, std::max(D.N, 4 * D.nIni));
-        // blur tiles
-        for (int ty = 0; ty < D.h; ty += BL_TH)
-            for (int tx = 0; tx < D.w; tx += BL_TW) o->tiles.push_back(TileInfo{(short)l, (short)tx, (short)ty, 0});
+        // blur tasks: one wavefront per (256-px column strip, BL_R-row block); right-edge reflect-101 selectors
+        for (int ty = 0; ty < D.h; ty += BL_R)
+            for (int gx = 0; gx * 4 < D.w; gx += 64) o->tiles.push_back(BlurTask{(short)l, (short)gx, (short)ty, 0});
+        {
+            static const u32 kSelB[4] = {0x05060700u, 0x07000100u, 0x01020100u, 0x03020100u};   // k = (w-1)&3 valid bytes-1
+            static const u32 kSelC[4] = {0x04040404u, 0x04040506u, 0x05060700u, 0x07000102u};
+            const int k = (D.w - 1) & 3;
+            o->blurSel.selB[l] = kSelB[k]; o->blurSel.selC[l] = kSelC[k];
+        }
         // resize taps from level l-1
         D.rzx = (int)o->xt.size(); D.rzy = (int)o->yt.size();
         if (l > 0) {
@@ -163,7 +214,38 @@ static int build_geometry(orbx* o, int w, int h) {
                 fy -= sy;
                 o->yt.push_back(RzTab{sy, sat((1.f - fy) * 2048.f), sat(fy * 2048.f)});
             }
+            // per-dword tables of the streaming kernel; it needs every tap pair inside 12 loaded bytes (offset <= 7)
+            while (o->x4.size() * 4 < (size_t)D.rzx) o->x4.push_back(RzX4{});
+            bool ok = (D.rzx % 4) == 0;
+            for (int gx = 0; gx * 4 < D.w && ok; ++gx) {
+                RzX4 e{};
+                const int first = o->xt[D.rzx + gx * 4].s;
+                e.bg = first >> 2;
+                for (int i = 0; i < 4; ++i) {
+                    const int dx = std::min(gx * 4 + i, D.w - 1);
+                    const RzTab& tb = o->xt[D.rzx + dx];
+                    const int off = tb.s - e.bg * 4;
+                    if (off < 0 || off > 7 || tb.a0 < 0 || tb.a1 < 0) { ok = false; break; }
+                    e.o[i] = (u8)off;
+                    e.a[i] = (u32)(unsigned short)tb.a0 | ((u32)(unsigned short)tb.a1 << 16);
+                }
+                o->x4.push_back(e);
+            }
+            // rows: strictly increasing source rows without clamping, and a bounded source span per task
+            for (int dy = 0; dy < D.h && ok; ++dy) {
+                const int sy = o->yt[D.rzy + dy].s;
+                if (sy < 0 || sy + 1 >= S.h || (dy > 0 && sy <= o->yt[D.rzy + dy - 1].s)) ok = false;
+            }
+            for (int ty = 0; ty < D.h && ok; ty += RZ_R) {
+                const int ye = std::min(ty + RZ_R, D.h);
+                if (o->yt[D.rzy + ye - 1].s + 2 - o->yt[D.rzy + ty].s > RZ_SRC) ok = false;
+            }
+            o->rzStream[l] = ok;
+            if (ok)
+                for (int ty = 0; ty < D.h; ty += RZ_R)
+                    for (int gx = 0; gx * 4 < D.w; gx += 64) o->rzTasks[l].push_back(RzTask{(short)l, (short)gx, (short)ty, 0});
         }
+        while (o->xt.size() % 4) o->xt.push_back(RzTab{0, 0, 0});      // keep every level's tap offset a multiple of 4
     }
     g.pyrFrameBytes = off;
     g.totalCells = (int)o->cells.size();
@@ -175,6 +257,15 @@ static int build_geometry(orbx* o, int w, int h) {
     g.sortCap = sc;
     if (g.nodeCap > 65000) { set_err("nfeatures per level %d too large for 16-bit node ids", maxN); return ORBX_E_UNSUPPORTED; }
     o->qtLds = (size_t)g.sortCap * 8 + (size_t)g.nodeCap * 56 + 64;
+    {   // k_quadtree2: list capacity max(N+3, 4*nIni) (+slack), power-of-two sort buffer
+        o->qt2Cap = maxN + 8;
+        int sc2 = 1; while (sc2 < o->qt2Cap) sc2 <<= 1;
+        o->qt2Sort = sc2;
+        o->maxCells = 0;
+        for (int l = 0; l < L; ++l) o->maxCells = std::max(o->maxCells, g.lv[l].nCells);
+        o->qt2Lds = (size_t)sc2 * 8 + (size_t)o->qt2Cap * (16 * 2 + 16 + 4 + 4 + 8 + 2 + 1 + 1) + (size_t)(o->maxCells + 1) * 4 + 64;
+        if (o->qt2Lds > 160 * 1024 - 512) { set_err("quadtree for %d features/level needs %zu B of LDS (> 160 KiB)", maxN, o->qt2Lds); return ORBX_E_UNSUPPORTED; }
+    }
     if (o->qtLds > 160 * 1024 - 512) { set_err("quadtree for %d features/level needs %zu B of LDS (> 160 KiB)", maxN, o->qtLds); return ORBX_E_UNSUPPORTED; }
     o->algBytes = sumSrc + sumDst + sumAll;      // read L0..L6 + write L1..L7 + read L0..L7
     o->fusedBytes = sumSrc + sumDst;
@@ -186,11 +277,21 @@ static int build_geometry(orbx* o, int w, int h) {
     if (ensure(&o->dL0, &o->capL0, (size_t)o->l0pitch * h * B)) return ORBX_E_HIP;
     if (ensure(&o->dCells, &o->capCells, o->cells.size())) return ORBX_E_HIP;
     if (ensure(&o->dTiles, &o->capTiles, o->tiles.size())) return ORBX_E_HIP;
+    if (ensure(&o->dStrips, &o->capStrips, o->strips.size())) return ORBX_E_HIP;
     if (ensure(&o->dXt, &o->capXt, std::max<size_t>(1, o->xt.size()))) return ORBX_E_HIP;
     if (ensure(&o->dYt, &o->capYt, std::max<size_t>(1, o->yt.size()))) return ORBX_E_HIP;
+    {
+        std::vector<RzTask> all;
+        for (int l = 0; l < L; ++l) { o->rzTaskOff[l] = (int)all.size(); all.insert(all.end(), o->rzTasks[l].begin(), o->rzTasks[l].end()); }
+        if (ensure(&o->dX4, &o->capX4, std::max<size_t>(1, o->x4.size()))) return ORBX_E_HIP;
+        if (ensure(&o->dRzTasks, &o->capRzTasks, std::max<size_t>(1, all.size()))) return ORBX_E_HIP;
+        if (!o->x4.empty()) HIPCHK(hipMemcpy(o->dX4, o->x4.data(), o->x4.size() * sizeof(RzX4), hipMemcpyHostToDevice));
+        if (!all.empty()) HIPCHK(hipMemcpy(o->dRzTasks, all.data(), all.size() * sizeof(RzTask), hipMemcpyHostToDevice));
+    }
     if (ensure(&o->dCandCnt, &o->capCandCnt, (size_t)g.totalCells * B)) return ORBX_E_HIP;
     { size_t c2 = 0; if (o->dKpNode) (void)hipFree(o->dKpNode); o->dKpNode = nullptr; if (ensure(&o->dKpNode, &c2, (size_t)g.totalSlots * B)) return ORBX_E_HIP; }
     if (ensure(&o->dCandEnt, &o->capCandEnt, (size_t)g.totalSlots * B)) return ORBX_E_HIP;
+    { size_t c2 = 0; if (o->dDense) (void)hipFree(o->dDense); o->dDense = nullptr; if (ensure(&o->dDense, &c2, (size_t)g.totalSlots * B)) return ORBX_E_HIP; }
     if (ensure(&o->dSel, &o->capSel, (size_t)g.totalSel * B)) return ORBX_E_HIP;
     {
         if (o->dKps) (void)hipFree(o->dKps); if (o->dDesc) (void)hipFree(o->dDesc); if (o->dWork) (void)hipFree(o->dWork);
@@ -200,10 +301,16 @@ static int build_geometry(orbx* o, int w, int h) {
         HIPCHK(hipMalloc((void**)&o->dWork, sizeof(KpWork) * g.kpCap * B));
     }
     HIPCHK(hipMemcpy(o->dCells, o->cells.data(), o->cells.size() * sizeof(CellInfo), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(o->dTiles, o->tiles.data(), o->tiles.size() * sizeof(TileInfo), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(o->dTiles, o->tiles.data(), o->tiles.size() * sizeof(BlurTask), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(o->dStrips, o->strips.data(), o->strips.size() * sizeof(StripInfo), hipMemcpyHostToDevice));
     if (!o->xt.empty()) HIPCHK(hipMemcpy(o->dXt, o->xt.data(), o->xt.size() * sizeof(RzTab), hipMemcpyHostToDevice));
     if (!o->yt.empty()) HIPCHK(hipMemcpy(o->dYt, o->yt.data(), o->yt.size() * sizeof(RzTab), hipMemcpyHostToDevice));
+    o->f3Tile = align_up(o->f3Tile, 16);
+    o->f3Lds = (size_t)2 * o->f3Tile + (size_t)(F3_NT / 64) * o->f3Qcap * 2;
+    if (o->f3Lds > 160 * 1024 - 256) { set_err("FAST strip needs %zu B of LDS", o->f3Lds); return ORBX_E_UNSUPPORTED; }
+    HIPCHK(hipFuncSetAttribute((const void*)k_fast3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->f3Lds));
     HIPCHK(hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->qtLds));
+    HIPCHK(hipFuncSetAttribute((const void*)k_quadtree2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->qt2Lds));
     o->curW = w; o->curH = h;
     return 0;
 }
@@ -233,6 +340,8 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     orbx* o = new orbx;
     o->nfeatures = nfeatures; o->nlevels = nlevels; o->iniTh = ini_th; o->minTh = min_th; o->device = device_id;
     o->maxW = max_w; o->maxH = max_h; o->maxBatch = max_batch;
+    o->fastV1 = getenv("ORBX_FAST_V1") != nullptr;
+    o->qtV1 = getenv("ORBX_QT_V1") != nullptr;            // A/B switch: simple per-cell reference kernel
     o->scaleFactor = scale_factor;                              // double member initialised from float (ORBextractor.h:96)
     const int L = nlevels;
     o->sf.resize(L); o->sig2.resize(L); o->invsf.resize(L); o->invsig2.resize(L); o->nfeat.resize(L);
@@ -259,7 +368,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
         if (hipMalloc((void**)&o->dL0Ptr, sizeof(u8*) * B) != hipSuccess || hipMalloc((void**)&o->dSelCnt, sizeof(u32) * 12 * B) != hipSuccess ||
             hipMalloc((void**)&o->dN, sizeof(int) * B) != hipSuccess || hipMalloc((void**)&o->dMono, sizeof(int) * B) != hipSuccess ||
             hipMalloc((void**)&o->dLap, sizeof(int) * 2 * B) != hipSuccess || hipMalloc((void**)&o->dErr, sizeof(int)) != hipSuccess ||
-            hipMalloc((void**)&o->dPattern, 1024) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
+            hipMalloc((void**)&o->dPattern, 1024) != hipSuccess || hipMalloc((void**)&o->dStamps, 64 * 8) != hipSuccess || hipMemset(o->dStamps, 0, 64 * 8) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
         if (hipMemcpy(o->dPattern, kPattern, 1024, hipMemcpyHostToDevice) != hipSuccess || hipMemset(o->dErr, 0, sizeof(int)) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMemcpy failed"); break; }
         o->hL0Ptr.resize(B); o->hLap.resize(2 * B);
         rc = build_geometry(o, max_w, max_h);
@@ -273,8 +382,8 @@ void orbx_destroy(orbx_t* o) {
     if (!o) return;
     (void)hipSetDevice(o->device);
     if (o->stream) (void)hipStreamSynchronize(o->stream);
-    void* ptrs[] = {o->dPyr, o->dBlur, o->dL0, (void*)o->dL0Ptr, o->dCells, o->dTiles, o->dXt, o->dYt, o->dCandCnt, o->dCandEnt,
-                    o->dSel, o->dSelCnt, o->dKpNode, o->dKps, o->dDesc, o->dWork, o->dN, o->dMono, o->dLap, o->dErr, o->dPattern};
+    void* ptrs[] = {o->dPyr, o->dBlur, o->dL0, (void*)o->dL0Ptr, o->dCells, o->dTiles, o->dStrips, o->dX4, o->dRzTasks, o->dXt, o->dYt, o->dCandCnt, o->dCandEnt,
+                    o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->dKps, o->dDesc, o->dWork, o->dN, o->dMono, o->dLap, o->dErr, o->dPattern, o->dStamps};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : o->ev) if (e) (void)hipEventDestroy(e);
     if (o->stream) (void)hipStreamDestroy(o->stream);
@@ -296,9 +405,18 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     const Geom& g = o->g;
     hipStream_t st = o->stream;
     int l0pitch;
-    if (img_space == ORBX_DEVICE) {
+    bool aligned = (stride % 16) == 0;
+    for (int i = 0; i < nimg && aligned; ++i) aligned = ((uintptr_t)imgs[i] % 16) == 0;
+    if (img_space == ORBX_DEVICE && aligned) {
         for (int i = 0; i < nimg; ++i) o->hL0Ptr[i] = imgs[i];
         l0pitch = stride;
+    } else if (img_space == ORBX_DEVICE) {                    // kernels use 16-byte row loads: stage misaligned inputs
+        for (int i = 0; i < nimg; ++i) {
+            u8* d = o->dL0 + (size_t)i * o->l0pitch * h;
+            HIPCHK(hipMemcpy2DAsync(d, o->l0pitch, imgs[i], stride, w, h, hipMemcpyDeviceToDevice, st));
+            o->hL0Ptr[i] = d;
+        }
+        l0pitch = o->l0pitch;
     } else {
         for (int i = 0; i < nimg; ++i) {
             u8* d = o->dL0 + (size_t)i * o->l0pitch * h;
@@ -313,19 +431,36 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
 
     HIPCHK(hipEventRecord(o->ev[0], st));
     for (int l = 1; l < g.nlevels; ++l) {
-        dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, nimg), block(64, 4);
-        hipLaunchKernelGGL(k_resize, grid, block, 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, l, o->dXt, o->dYt);
+        if (o->rzStream[l]) {
+            const int nt = (int)o->rzTasks[l].size();
+            hipLaunchKernelGGL(k_resize2, dim3((nt + 3) / 4, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr,
+                               o->dRzTasks + o->rzTaskOff[l], nt, o->dX4, o->dYt);
+        } else {                                                 // general fallback (large scale factors, tight level-0 strides)
+            dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, nimg), block(64, 4);
+            hipLaunchKernelGGL(k_resize, grid, block, 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, l, o->dXt, o->dYt);
+        }
     }
     HIPCHK(hipEventRecord(o->ev[1], st));
-    hipLaunchKernelGGL(k_fast, dim3(g.totalCells, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dCells,
-                       o->dCandCnt, o->dCandEnt, o->dErr);
+    if (o->fastV1)
+        hipLaunchKernelGGL(k_fast, dim3(g.totalCells, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dCells,
+                           o->dCandCnt, o->dCandEnt, o->dErr);
+    else
+        hipLaunchKernelGGL(k_fast3, dim3((unsigned)o->strips.size(), nimg), dim3(F3_NT), o->f3Lds, st, g, o->dL0Ptr, l0pitch, o->dPyr,
+                           o->dCells, o->dStrips, o->dCandCnt, o->dCandEnt, o->dErr, o->f3Tile, o->f3Qcap);
     HIPCHK(hipEventRecord(o->ev[2], st));
-    hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, nimg), dim3(256), o->qtLds, st, g, o->dCells, o->dCandCnt, o->dCandEnt,
-                       o->dKpNode, o->dSel, o->dSelCnt, o->dErr);
+    if (o->qtV1)
+        hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, nimg), dim3(256), o->qtLds, st, g, o->dCells, o->dCandCnt, o->dCandEnt,
+                           o->dKpNode, o->dSel, o->dSelCnt, o->dErr);
+    else {
+        Geom g2 = g; g2.nodeCap = o->qt2Cap; g2.sortCap = o->qt2Sort;
+        hipLaunchKernelGGL(k_quadtree2, dim3(g.nlevels, nimg), dim3(256), o->qt2Lds, st, g2, o->dCandCnt, o->dCandEnt,
+                           o->dDense, o->dKpNode, o->dSel, o->dSelCnt, o->dErr, o->maxCells);
+    }
     HIPCHK(hipEventRecord(o->ev[3], st));
     hipLaunchKernelGGL(k_slots, dim3(nimg), dim3(256), 0, st, g, o->dSel, o->dSelCnt, o->dLap, o->dKps, o->dWork, o->dN, o->dMono);
     HIPCHK(hipEventRecord(o->ev[4], st));
-    hipLaunchKernelGGL(k_blur, dim3((unsigned)o->tiles.size(), nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur, o->dTiles);
+    hipLaunchKernelGGL(k_blur2, dim3((unsigned)(o->tiles.size() + 3) / 4, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
+                       o->dTiles, (int)o->tiles.size(), o->blurSel);
     HIPCHK(hipEventRecord(o->ev[5], st));
     hipLaunchKernelGGL(k_orient_desc, dim3((g.kpCap + 3) / 4, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
                        o->dWork, o->dN, o->dKps, o->dDesc, o->dPattern, o->umax);
@@ -482,6 +617,15 @@ int64_t orbx_algorithmic_bytes(const orbx_t* o, int64_t* fused_lower_bound) {
     if (!o) return ORBX_E_INVALID;
     if (fused_lower_bound) *fused_lower_bound = o->fusedBytes;
     return o->algBytes;
+}
+
+int orbx_debug_stamps(orbx_t* o, unsigned long long* out, int n) {
+    if (!o || n > 64) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    HIPCHK(hipStreamSynchronize(o->stream));
+    HIPCHK(hipMemcpy(out, o->dStamps, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(o->dStamps, 0, 64 * 8));
+    return ORBX_OK;
 }
 
 void* orbx_stream(const orbx_t* o) { return o ? (void*)o->stream : nullptr; }

@@ -19,6 +19,7 @@ typedef uint32_t u32;
 typedef uint16_t u16;
 typedef uint8_t u8;
 
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 struct RzTab { int s; short a0, a1; };                     // source index + two Q11 taps (8 bytes)
 
 struct LevelDesc {                                         // one pyramid level of the current geometry
@@ -51,9 +52,29 @@ struct Geom {                                              // kernel argument bl
     LevelDesc lv[12];
 };
 
+__device__ __forceinline__ us2 as_us2(u32 v) { return __builtin_bit_cast(us2, v); }
+__device__ __forceinline__ u32 as_u32(us2 v) { return __builtin_bit_cast(u32, v); }
+__device__ __forceinline__ us2 pkmin(us2 a, us2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ us2 pkmax(us2 a, us2 b) { return __builtin_elementwise_max(a, b); }
+
+// Loads through an explicit global address space: pointers fetched from memory (the per-frame level-0 table)
+// are generic to the compiler, which would emit flat_load + conservative vmcnt(0)/lgkmcnt(0) waits.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ u32 gload32(const void* p) { return *(const __attribute__((address_space(1))) u32*)p; }
+__device__ __forceinline__ uint4 gload128(const void* p) { return *(const __attribute__((address_space(1))) uint4*)p; }
+__device__ __forceinline__ u8 gload8(const void* p) { return *(const __attribute__((address_space(1))) u8*)p; }
+#else
+__device__ __forceinline__ u32 gload32(const void* p) { return *(const u32*)p; }
+__device__ __forceinline__ uint4 gload128(const void* p) { return *(const uint4*)p; }
+__device__ __forceinline__ u8 gload8(const void* p) { return *(const u8*)p; }
+#endif
+
 __device__ __forceinline__ const u8* level_ptr(const Geom& g, const u8* const* l0, int l0pitch,
                                                const u8* pyr, int frame, int level, int* pitch) {
-    if (level == 0) { *pitch = l0pitch; return l0[frame]; }
+    if (level == 0) {
+        *pitch = l0pitch;
+        return l0[frame];
+    }
     *pitch = g.lv[level].pitch;
     return pyr + (size_t)frame * g.pyrFrameBytes + g.lv[level].off;
 }
@@ -95,6 +116,91 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, const u8* const* l0, int
     u8* o = dst + (size_t)dy * D.pitch + dx0;
     if (dx0 + 3 < D.pitch) *(u32*)o = packed;              // pitch is a multiple of 64: the padding absorbs the tail
     else for (int i = 0; i < 4 && dx0 + i < D.w; ++i) o[i] = (u8)(packed >> (8 * i));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_resize2: streaming form of the same arithmetic.  One wavefront owns 256 destination pixels of a row
+// (4 px per lane, stored as one dword) and walks RZ_R destination rows downwards.  Per SOURCE row a lane
+// loads 12 contiguous bytes (3 dwords) that cover its 4 tap pairs; the pair for pixel i is cut out with
+// v_alignbit at a per-lane constant offset and reduced with one v_dot2_u32_u16 against (a0,a1).  The
+// horizontal result of source row sy+1 is reused as row sy of the next destination row (the reference's
+// cv::resize keeps the same two-row cache).  Row taps come from the scalar unit (wave-uniform).
+// ------------------------------------------------------------------------------------------------
+#define RZ_R 8
+#define RZ_SRC 12                                          // source rows one task may touch (host checks)
+struct RzX4 { int bg; u8 o[4]; u32 a[4]; };                // per destination dword: base source dword, byte offsets, (a0 | a1<<16)
+struct RzTask { short level, g0, y0, pad; };
+
+__global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, int l0pitch, u8* pyr,
+                                                 const RzTask* __restrict__ tasks, int ntasks,
+                                                 const RzX4* __restrict__ x4, const RzTab* __restrict__ yt) {
+    const int lane = threadIdx.x & 63;
+    const int ti = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ti >= ntasks) return;
+    RzTask t = tasks[ti];
+    const int level = __builtin_amdgcn_readfirstlane(t.level);
+    const int g0 = __builtin_amdgcn_readfirstlane(t.g0), y0 = __builtin_amdgcn_readfirstlane(t.y0);
+    const int frame = blockIdx.y;
+    const LevelDesc& D = g.lv[level];
+    const LevelDesc& S = g.lv[level - 1];
+    int sp;
+    const u8* src = level_ptr(g, l0, l0pitch, pyr, frame, level - 1, &sp);
+    u8* dst = pyr + (size_t)frame * g.pyrFrameBytes + D.off;
+    const int gcol = g0 + lane;
+    const int ndw = (D.w + 3) >> 2;
+    const bool act = gcol < ndw;
+    const RzX4 X = x4[D.rzx / 4 + (act ? gcol : ndw - 1)];   // rzx is the level's offset in pixels; the x4 table is per dword
+    u32 sh[4]; bool hiSel[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sh[i] = (X.o[i] & 3u) * 8u; hiSel[i] = X.o[i] >= 4; }
+    const u8* colp = src + (size_t)X.bg * 4;
+    const bool ld1 = X.bg * 4 + 8 <= sp, ld2 = X.bg * 4 + 12 <= sp;     // taps beyond the row are never used; do not read them
+    const int yend = min(y0 + RZ_R, D.h);
+    const int sFirst = yt[D.rzy + y0].s;
+    const int nsrc = yt[D.rzy + yend - 1].s + 2 - sFirst;               // host guarantees 0 <= s, s+1 < S.h, nsrc <= RZ_SRC
+    // all source rows of the task in flight before any arithmetic
+    u32 d0[RZ_SRC], d1[RZ_SRC], d2[RZ_SRC];
+#pragma unroll
+    for (int j = 0; j < RZ_SRC; ++j) {
+        d0[j] = d1[j] = d2[j] = 0;
+        if (j < nsrc) {
+            const u8* p = colp + (size_t)(sFirst + j) * sp;
+            d0[j] = gload32(p);
+            if (ld1) d1[j] = gload32(p + 4);
+            if (ld2) d2[j] = gload32(p + 8);
+        }
+    }
+    int Hp[4] = {0, 0, 0, 0};
+    int dy = y0;
+#pragma unroll
+    for (int j = 0; j < RZ_SRC; ++j) {
+        if (j < nsrc) {
+            int Hc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32 lo = hiSel[i] ? d1[j] : d0[j], hi = hiSel[i] ? d2[j] : d1[j];
+                const u32 pair = __builtin_amdgcn_alignbit(hi, lo, sh[i]);
+                const us2 s2 = as_us2(__builtin_amdgcn_perm(0, pair, 0x0c010c00u));
+                Hc[i] = (int)__builtin_amdgcn_udot2(s2, as_us2(X.a[i]), 0u, false);
+            }
+            if (dy < yend) {
+                const RzTab ty = yt[D.rzy + dy];
+                if (ty.s + 1 == sFirst + j) {                       // rows (sy, sy+1) = (j-1, j) are both here: emit dy
+                    u32 packed = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        int v = (((ty.a0 * (Hp[i] >> 4)) >> 16) + ((ty.a1 * (Hc[i] >> 4)) >> 16) + 2) >> 2;
+                        v = min(max(v, 0), 255);
+                        packed |= (u32)v << (8 * i);
+                    }
+                    if (act) *(u32*)(dst + (size_t)dy * D.pitch + gcol * 4) = packed;
+                    ++dy;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Hp[i] = Hc[i];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -204,6 +310,160 @@ __global__ __launch_bounds__(256) void k_fast(Geom g, const u8* const* l0, int l
         __syncthreads();
     }
     if (tid == 0) candCnt[(size_t)frame * g.totalCells + c.cnt] = (u32)base;
+}
+
+struct StripInfo { short level, ncell, x0, y0, w, h, xal, lp; int cell0; };   // lp = LDS tile pitch in bytes
+
+// ------------------------------------------------------------------------------------------------
+// k_fast3: strip tile shared by the workgroup, but every FAST cell is processed by ONE wavefront with no
+// workgroup barrier after the tile load (k_fast2 spent its time parked at 7 barriers with 2 WGs/CU).
+// Per cell the wave replays the reference literally: cv::FAST at iniTh, and only if that leaves the cell
+// empty AFTER non-max suppression, cv::FAST at minTh (ORBextractor.cc:1112-1125):
+//   quick reject (packed 16-bit, 4 px per lane) -> ballot compaction into the wave's LDS queue ->
+//   exact score on dense lanes, in-place compaction of pixels with S >= t -> strict 3x3 maxima inside the
+//   cell window, compacted again -> row-major rank by counting (queue keys are row-major) -> packed store.
+// No atomics, no bitmap: all counts live in wave-uniform registers.
+// ------------------------------------------------------------------------------------------------
+#define F3_NT 512
+__global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
+                                                 const CellInfo* __restrict__ cells, const StripInfo* __restrict__ strips,
+                                                 u32* candCnt, u32* candEnt, int* err, int tileBytes, int qcap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char f3smem[];
+    u8* img = f3smem;
+    u8* sc = f3smem + tileBytes;
+    StripInfo st = strips[blockIdx.x];
+    st.level = (short)__builtin_amdgcn_readfirstlane(st.level);
+    const int frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    u16* q = (u16*)(f3smem + 2 * tileBytes) + wv * qcap;
+    const int Pb = st.lp, H = st.h;                                       // lp holds the tile pitch in bytes here
+    int sp;
+    const u8* src = level_ptr(g, l0, l0pitch, pyr, frame, st.level, &sp);
+    const LevelDesc& L = g.lv[st.level];
+    {   // tile load: 32 lanes x 16 B per row
+        const int cpr = Pb >> 4;
+        const int rowLimit = min((L.w + 15) & ~15, sp);
+        const int ck = tid & 31;
+        for (int r = tid >> 5; r < H; r += F3_NT / 32) {
+            if (ck < cpr) {
+                const int gx = st.xal + ck * 16;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (gx < rowLimit) v = gload128(src + (size_t)(st.y0 + r) * sp + gx);
+                *(uint4*)(img + r * Pb + ck * 16) = v;
+                *(uint4*)(sc + r * Pb + ck * 16) = make_uint4(0, 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int c = wv; c < st.ncell; c += F3_NT / 64) {
+        const CellInfo cell = cells[st.cell0 + c];
+        const int cx0 = cell.x0 + 3 - st.xal, cx1 = cell.x0 + cell.cw - 3 - st.xal;   // valid columns (tile coords)
+        const int vy0 = 3, vy1 = H - 3;
+        int n3 = 0;
+        if (cx1 > cx0 && vy1 > vy0) {
+            const int gx0 = cx0 >> 2, ng = ((cx1 + 3) >> 2) - gx0, total = ng * (vy1 - vy0);
+            const float inv = 1.0f / (float)ng;
+            for (int pass = 0; pass < 2; ++pass) {
+                const int t = pass == 0 ? g.iniTh : g.minTh;
+                if (pass == 1 && g.minTh >= g.iniTh) break;               // a higher retry threshold cannot add corners
+                const u32 tt = (u32)t * 0x00010001u;
+                // ---- quick reject + compaction
+                int n1 = 0;
+                for (int gi0 = 0; gi0 < total; gi0 += 64) {
+                    const int gi = gi0 + lane;
+                    u32 m = 0;
+                    int ty = 0, tx = 0;
+                    if (gi < total) {
+                        int ry = (int)((float)gi * inv);
+                        int rem = gi - ry * ng;
+                        if (rem < 0) { --ry; rem += ng; } else if (rem >= ng) { ++ry; rem -= ng; }
+                        ty = vy0 + ry; tx = (gx0 + rem) << 2;
+                        const u32* rowc = (const u32*)(img + ty * Pb);
+                        const u32 B = rowc[tx >> 2], A = rowc[(tx >> 2) - 1], Cw = rowc[(tx >> 2) + 1];
+                        const u32 U = *(const u32*)(img + (ty - 3) * Pb + tx), D = *(const u32*)(img + (ty + 3) * Pb + tx);
+                        const u32 Lw = __builtin_amdgcn_alignbyte(B, A, 1);
+                        const u32 Rw = __builtin_amdgcn_alignbyte(Cw, B, 3);
+#pragma unroll
+                        for (int hlf = 0; hlf < 2; ++hlf) {
+                            const u32 sel = hlf ? 0x0c030c02u : 0x0c010c00u;
+                            const us2 v = as_us2(__builtin_amdgcn_perm(0, B, sel)), up = as_us2(__builtin_amdgcn_perm(0, U, sel)),
+                                      dn = as_us2(__builtin_amdgcn_perm(0, D, sel)), lf = as_us2(__builtin_amdgcn_perm(0, Lw, sel)),
+                                      rt = as_us2(__builtin_amdgcn_perm(0, Rw, sel));
+                            const us2 t2 = as_us2(tt);
+                            const us2 X = pkmax(pkmin(up, dn), pkmin(lf, rt));
+                            const us2 Y = pkmin(pkmax(up, dn), pkmax(lf, rt));
+                            const u32 rr = as_u32((X - (v - t2)) | ((v + t2) - Y));
+                            m |= (((rr >> 15) & 1u) | ((rr >> 30) & 2u)) << (2 * hlf);
+                        }
+                        u32 vm = 0xFu;
+                        if (tx < cx0) vm &= 0xFu << (cx0 - tx);
+                        if (tx + 4 > cx1) vm &= 0xFu >> (tx + 4 - cx1);
+                        m &= vm;
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const bool f = (m >> b) & 1u;
+                        const unsigned long long bal = __ballot(f);
+                        if (f) q[n1 + __popcll(bal & lt)] = (u16)((ty << 9) | (tx + b));
+                        n1 += __popcll(bal);
+                    }
+                }
+                // ---- exact score; keep pixels with S >= t (in place)
+                int n2 = 0;
+                for (int e0 = 0; e0 < n1; e0 += 64) {
+                    const int e = e0 + lane;
+                    bool f = false;
+                    int pq = 0;
+                    if (e < n1) {
+                        pq = q[e];
+                        const int px = (pq >> 9) * Pb + (pq & 511);
+                        const int s = fast_score16(img + px, Pb);
+                        f = s >= t;
+                        if (f) sc[px] = (u8)s;
+                    }
+                    const unsigned long long bal = __ballot(f);
+                    if (f) q[n2 + __popcll(bal & lt)] = (u16)pq;
+                    n2 += __popcll(bal);
+                }
+                // ---- strict 3x3 maxima inside the cell window (in place)
+                n3 = 0;
+                for (int e0 = 0; e0 < n2; e0 += 64) {
+                    const int e = e0 + lane;
+                    bool keep = false;
+                    int pq = 0;
+                    if (e < n2) {
+                        pq = q[e];
+                        const int tx = pq & 511;
+                        const u8* p = sc + (pq >> 9) * Pb + tx;
+                        const int s = p[0];
+                        keep = s > p[-Pb] && s > p[Pb];
+                        if (tx > cx0) keep = keep && s > p[-1] && s > p[-Pb - 1] && s > p[Pb - 1];
+                        if (tx < cx1 - 1) keep = keep && s > p[1] && s > p[-Pb + 1] && s > p[Pb + 1];
+                    }
+                    const unsigned long long bal = __ballot(keep);
+                    if (keep) q[n3 + __popcll(bal & lt)] = (u16)pq;
+                    n3 += __popcll(bal);
+                }
+                if (n3 > 0) break;
+            }
+        }
+        // ---- row-major rank (queue keys ty<<9|tx are row-major) and packed store
+        u32* out = candEnt + (size_t)frame * g.totalSlots + cell.slot;
+        for (int e0 = 0; e0 < n3; e0 += 64) {
+            const int e = e0 + lane;
+            const int my = e < n3 ? q[e] : 0xFFFF;
+            int rank = 0;
+            for (int j = 0; j < n3; ++j) rank += q[j] < my;
+            if (e < n3) {
+                const int tx = my & 511, ty = my >> 9;
+                const int s = sc[ty * Pb + tx];
+                if (rank < L.slotCap)
+                    out[rank] = (u32)(st.xal + tx - 16) | ((u32)(st.y0 + ty - 16) << 12) | ((u32)s << 24);
+                else atomicExch(err, 1);
+            }
+        }
+        if (lane == 0) candCnt[(size_t)frame * g.totalCells + cell.cnt] = (u32)n3;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -453,6 +713,258 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const CellInfo* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_quadtree2: the same DistributeOctTree, with the list surgery itself data-parallel.
+// The std::list is an ARRAY in list order; a node's id is its position.  One refinement pass =
+//   quadrant histograms (parallel over candidates) -> per-node child counts -> block scans that give every
+//   child / surviving node its position in the NEXT list (children of later parents go further to the front,
+//   inside a parent n4,n3,n2,n1: exactly what push_front in the order n1..n4 produces) -> keypoints relabelled.
+// Final phase (ORBextractor.cc:912-992): candidates sorted by (count, creation seq) with a bitonic sort, the
+// early `break` at N becomes a prefix-scan cut.  Node tables ping-pong between two LDS buffers.
+// Output order and content are identical to k_quadtree (kept for A/B), at ~1/20 of its latency.
+// ------------------------------------------------------------------------------------------------
+struct QNode { short4 r; u32 cnt; u32 seq; };
+
+__device__ __forceinline__ u32 block_scan_excl(u32* a, int n, u32* wsum, int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const int per = (n + 255) >> 8;
+    const int b = min(tid * per, n), e = min(b + per, n);
+    u32 s = 0;
+    for (int i = b; i < e; ++i) s += a[i];
+    u32 inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    __syncthreads();                                       // wsum may still be read from a previous call
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    u32 base = 0;
+    for (int k = 0; k < wv; ++k) base += wsum[k];
+    const u32 total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    u32 run = base + inc - s;
+    for (int i = b; i < e; ++i) { const u32 v = a[i]; a[i] = run; run += v; }
+    __syncthreads();
+    return total;
+}
+
+__device__ __forceinline__ short4 qt_child_rect(short4 r, int q) {
+    const int hx = (r.z - r.x + 1) >> 1, hy = (r.w - r.y + 1) >> 1;
+    const int mx = r.x + hx, my = r.y + hy;
+    return make_short4((short)((q & 1) ? mx : r.x), (short)((q & 2) ? my : r.y),
+                       (short)((q & 1) ? r.z : mx), (short)((q & 2) ? r.w : my));
+}
+
+__global__ __launch_bounds__(256) void k_quadtree2(Geom g, const u32* __restrict__ candCnt, const u32* __restrict__ candEnt,
+                                                   u32* dense, u16* kpNode, u32* selOut, u32* selCnt, int* err, int maxCells) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int level = blockIdx.x, frame = blockIdx.y;
+    const LevelDesc& L = g.lv[level];
+    const int tid = threadIdx.x;
+    const int cap = g.nodeCap, n2cap = g.sortCap;
+    unsigned long long* sortKey = (unsigned long long*)smem;
+    QNode* tabA = (QNode*)(sortKey + n2cap);
+    QNode* tabB = tabA + cap;
+    u32* qc = (u32*)(tabB + cap);                           // [cap][4]; reused as best[] at the end
+    u32* s1 = qc + cap * 4;
+    u32* s2 = s1 + cap;
+    u32* cellOff = s2 + cap;                                // [maxCells + 1]
+    u16* childPos = (u16*)(cellOff + maxCells + 1);         // [cap][4]
+    u16* newPos = childPos + cap * 4;
+    u8* nch = (u8*)(newPos + cap);
+    u8* proc = nch + cap;
+    __shared__ u32 wsum[4];
+    __shared__ int s_size, s_state, s_seqBase, s_cnt, s_ncand;
+    const u32* cnts = candCnt + (size_t)frame * g.totalCells + L.cellBase;
+    const u32* ents = candEnt + (size_t)frame * g.totalSlots + L.slotBase;
+    u32* de = dense + (size_t)frame * g.totalSlots + L.slotBase;     // candidates of this level, densely packed in
+    u16* kn = kpNode + (size_t)frame * g.totalSlots + L.slotBase;    // vToDistributeKeys order; their current node
+    const int N = L.N;
+
+    // ---- gather the per-cell slot arrays into one dense list (cells are stored in reference order)
+    const int nCells = L.nCells;
+    for (int c = tid; c < nCells; c += 256) cellOff[c] = cnts[c];
+    for (int i = tid; i < cap; i += 256) s1[i] = 0;
+    __syncthreads();
+    const int nk = (int)block_scan_excl(cellOff, nCells, wsum, tid);
+    if (tid == 0) cellOff[nCells] = (u32)nk;
+    __syncthreads();
+    for (int i = tid; i < nk; i += 256) {
+        int lo = 0, hi = nCells;                             // last cell with cellOff <= i
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)cellOff[mid] <= i) lo = mid; else hi = mid; }
+        const u32 e = ents[lo * L.slotCap + (i - (int)cellOff[lo])];
+        de[i] = e;
+        const int root = (int)((float)(e & 0xFFF) / L.hX);  // ORBextractor.cc:740
+        kn[i] = (u16)root;
+        atomicAdd(&s1[root], 1u);
+    }
+    __syncthreads();
+
+#define QT_FOR_KP(BODY) for (int ki = tid; ki < nk; ki += 256) { const u32 e = de[ki]; BODY }
+
+    // ---- roots (ORBextractor.cc:695-763)
+    if (tid == 0) {
+        int size = 0;
+        for (int i = 0; i < L.nIni; ++i) {
+            if (s1[i] == 0) { newPos[i] = 0xFFFF; continue; }     // empty roots are erased
+            QNode nd;
+            nd.r = make_short4((short)(int)(L.hX * (float)i), 0, (short)(int)(L.hX * (float)(i + 1)), (short)L.qtH);
+            nd.cnt = s1[i]; nd.seq = i;
+            tabA[size] = nd; newPos[i] = (u16)size; ++size;
+        }
+        s_size = size; s_state = 0; s_seqBase = L.nIni; s_cnt = 0;
+    }
+    __syncthreads();
+    QT_FOR_KP({ (void)e; kn[ki] = newPos[kn[ki]]; })
+    __syncthreads();
+
+    QNode* A = tabA; QNode* B = tabB;
+    for (int iter = 0;; ++iter) {
+        const int state = s_state, size = s_size;
+        if (state == 2) break;
+        if (iter > 4096) { if (tid == 0) atomicExch(err, 4); break; }
+        // (1) quadrant histograms of every splittable node
+        for (int i = tid; i < size * 4; i += 256) qc[i] = 0;
+        if (tid == 0) { s_cnt = 0; s_ncand = 0; }
+        __syncthreads();
+        QT_FOR_KP({ const int nd = kn[ki]; if (A[nd].cnt > 1) atomicAdd(&qc[nd * 4 + qt_quadrant(A[nd].r, e & 0xFFF, (e >> 12) & 0xFFF)], 1u); })
+        __syncthreads();
+        int totalCh = 0, newSize = 0;
+        if (state == 0) {                                                    // ORBextractor.cc:779-895
+            for (int i = tid; i < size; i += 256) {
+                int c = 0;
+                if (A[i].cnt > 1) c = (qc[i * 4] > 0) + (qc[i * 4 + 1] > 0) + (qc[i * 4 + 2] > 0) + (qc[i * 4 + 3] > 0);
+                nch[i] = (u8)c; proc[i] = c > 0;
+                s1[i] = c; s2[i] = c > 0 ? 0 : 1;
+            }
+            __syncthreads();
+            totalCh = (int)block_scan_excl(s1, size, wsum, tid);
+            const int totalKeep = (int)block_scan_excl(s2, size, wsum, tid);
+            newSize = totalCh + totalKeep;
+            for (int i = tid; i < size; i += 256) {
+                const int c = nch[i];
+                if (c > 0) {
+                    const int blockStart = totalCh - (int)s1[i] - c;
+                    int fwd = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const u32 qn = qc[i * 4 + q];
+                        if (qn > 0) {
+                            const int pos = blockStart + (c - 1 - fwd);
+                            QNode nd; nd.r = qt_child_rect(A[i].r, q); nd.cnt = qn; nd.seq = (u32)(s_seqBase + (int)s1[i] + fwd);
+                            B[pos] = nd; childPos[i * 4 + q] = (u16)pos;
+                            if (qn > 1) atomicAdd(&s_cnt, 1);
+                            ++fwd;
+                        }
+                    }
+                } else {
+                    const int pos = totalCh + (int)s2[i];
+                    B[pos] = A[i]; newPos[i] = (u16)pos;
+                }
+            }
+        } else {                                                             // ORBextractor.cc:912-992
+            int n2 = 1;
+            while (n2 < size) n2 <<= 1;
+            for (int i = tid; i < n2; i += 256) {
+                unsigned long long key = 0;
+                if (i < size && A[i].cnt > 1) {
+                    key = ((unsigned long long)A[i].cnt << 40) | ((unsigned long long)A[i].seq << 16) | (unsigned)i;
+                    atomicAdd(&s_ncand, 1);
+                }
+                sortKey[i] = key;
+                if (i < size) {
+                    int c = 0;
+                    if (A[i].cnt > 1) c = (qc[i * 4] > 0) + (qc[i * 4 + 1] > 0) + (qc[i * 4 + 2] > 0) + (qc[i * 4 + 3] > 0);
+                    nch[i] = (u8)c; proc[i] = 0;
+                }
+            }
+            __syncthreads();
+            for (int k = 2; k <= n2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < n2; i += 256) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const unsigned long long a = sortKey[i], b = sortKey[ixj];
+                            const bool up = (i & k) == 0;
+                            if ((a > b) == up) { sortKey[i] = b; sortKey[ixj] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            const int ncand = s_ncand;
+            // processing order k = 0.. : largest (count, seq) first = sortKey[n2-1-k]
+            for (int k = tid; k < ncand; k += 256) s1[k] = (u32)nch[(int)(sortKey[n2 - 1 - k] & 0xFFFF)] - 1u;
+            __syncthreads();
+            block_scan_excl(s1, ncand, wsum, tid);
+            // the reference stops right after the split that makes size >= N: count the splits that leave size < N
+            for (int k = tid; k < ncand; k += 256) {
+                const int gain = (int)nch[(int)(sortKey[n2 - 1 - k] & 0xFFFF)] - 1;
+                if (size + (int)s1[k] + gain < N) atomicAdd(&s_cnt, 1);
+            }
+            __syncthreads();
+            const int P = min(ncand, s_cnt + 1);
+            __syncthreads();
+            if (tid == 0) s_cnt = 0;
+            for (int k = tid; k < ncand; k += 256) {
+                const int id = (int)(sortKey[n2 - 1 - k] & 0xFFFF);
+                s1[k] = k < P ? (u32)nch[id] : 0u;
+                if (k < P) proc[id] = 1;
+            }
+            __syncthreads();
+            for (int i = tid; i < size; i += 256) s2[i] = proc[i] ? 0 : 1;
+            __syncthreads();
+            totalCh = (int)block_scan_excl(s1, ncand, wsum, tid);
+            const int totalKeep = (int)block_scan_excl(s2, size, wsum, tid);
+            newSize = totalCh + totalKeep;
+            for (int k = tid; k < P; k += 256) {
+                const int i = (int)(sortKey[n2 - 1 - k] & 0xFFFF);
+                const int c = nch[i];
+                const int blockStart = totalCh - (int)s1[k] - c;
+                int fwd = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32 qn = qc[i * 4 + q];
+                    if (qn > 0) {
+                        const int pos = blockStart + (c - 1 - fwd);
+                        QNode nd; nd.r = qt_child_rect(A[i].r, q); nd.cnt = qn; nd.seq = (u32)(s_seqBase + (int)s1[k] + fwd);
+                        B[pos] = nd; childPos[i * 4 + q] = (u16)pos;
+                        ++fwd;
+                    }
+                }
+            }
+            for (int i = tid; i < size; i += 256)
+                if (!proc[i]) { const int pos = totalCh + (int)s2[i]; B[pos] = A[i]; newPos[i] = (u16)pos; }
+        }
+        __syncthreads();
+        // (3) relabel the keypoints
+        QT_FOR_KP({ const int nd = kn[ki];
+                    kn[ki] = proc[nd] ? childPos[nd * 4 + qt_quadrant(A[nd].r, e & 0xFFF, (e >> 12) & 0xFFF)] : newPos[nd]; })
+        __syncthreads();
+        if (tid == 0) {
+            const int nToExpand = s_cnt;
+            s_seqBase += totalCh;
+            s_size = newSize;
+            if (newSize > cap) { atomicExch(err, 2); s_state = 2; }
+            else if (newSize >= N || newSize == size) s_state = 2;
+            else if (state == 0 && newSize + nToExpand * 3 > N) s_state = 1;
+        }
+        QNode* t_ = A; A = B; B = t_;
+        __syncthreads();
+    }
+    // ---- one keypoint per node: first maximum of `response` in candidate order (ORBextractor.cc:1005-1030)
+    const int nsel = s_size;
+    u32* best = qc;
+    for (int i = tid; i < nsel; i += 256) best[i] = 0;
+    __syncthreads();
+    QT_FOR_KP({ atomicMax(&best[kn[ki]], ((e >> 24) << 24) | (0xFFFFFFu - (u32)ki)); })
+    __syncthreads();
+    u32* so = selOut + (size_t)frame * g.totalSel + L.selBase;
+    for (int i = tid; i < nsel; i += 256) {
+        if (i < L.selCap) so[i] = de[0xFFFFFFu - (best[i] & 0xFFFFFFu)];
+        else atomicExch(err, 3);
+    }
+    if (tid == 0) selCnt[frame * g.nlevels + level] = (u32)min(nsel, L.selCap);
+#undef QT_FOR_KP
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_slots: one workgroup per frame.  Walks the levels in order, fixes up coordinates/octave/size
 // (ORBextractor.cc:1161-1176), scales to level-0 coordinates and assigns the output row:
 // lapping keypoints fill the output from the back, the rest from the front (:1633-1655).
@@ -519,45 +1031,97 @@ __global__ __launch_bounds__(256) void k_slots(Geom g, const u32* __restrict__ s
 // horizontal pass exact in Q8.8, vertical pass to Q16.16, one rounding (+32768)>>16.
 // Tile 64x32 outputs per workgroup, source window (70x38) staged in LDS.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int reflect101(int p, int n) {
-    if (n == 1) return 0;
-    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
-    return p;
+__device__ __forceinline__ int reflect101(int p, int n) {   // valid for -n < p < 2n-1 (callers stay within 3 px)
+    p = p < 0 ? -p : p;
+    return p >= n ? 2 * n - 2 - p : p;
 }
 
-#define BL_TW 64
-#define BL_TH 32
-__global__ __launch_bounds__(256) void k_blur(Geom g, const u8* const* l0, int l0pitch, const u8* pyr, u8* blr,
-                                              const TileInfo* __restrict__ tiles) {
-    __shared__ u8 src[(BL_TH + 6) * (BL_TW + 8)];
-    __shared__ u16 hb[(BL_TH + 6) * BL_TW];
-    const TileInfo t = tiles[blockIdx.x];
-    const int frame = blockIdx.y, tid = threadIdx.x;
+// Streaming form: one wavefront owns a 256-pixel-wide column strip (4 px per lane, one dword) and walks
+// BL_R output rows downwards.  Per source row: ONE coalesced dword load per lane, neighbours' dwords through
+// __shfl (no LDS), horizontal 7-tap as two v_dot4_u32_u8 per pixel, then the vertical 7-tap over a rotating
+// 7-row register window.  Reflect-101 at the left/right image edge is done with v_perm selectors chosen on
+// the host from (width & 3); rows reflect through the row index.
+#define BL_R 32
+struct BlurTask { short level, g0, y0, pad; };            // g0 = first dword column of the strip, y0 = first output row
+
+struct BlurSel { u32 selB[12], selC[12]; };               // per level: right-edge fix-up selectors
+
+__global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int l0pitch, const u8* pyr, u8* blr,
+                                               const BlurTask* __restrict__ tasks, int ntasks, BlurSel bs) {
+    const int lane = threadIdx.x & 63;
+    const int ti = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ti >= ntasks) return;
+    BlurTask t = tasks[ti];
+    t.level = (short)__builtin_amdgcn_readfirstlane(t.level);   // wave-uniform: keeps Geom indexing on the scalar unit
+    t.g0 = (short)__builtin_amdgcn_readfirstlane(t.g0);
+    t.y0 = (short)__builtin_amdgcn_readfirstlane(t.y0);
+    const int frame = blockIdx.y;
     const LevelDesc& L = g.lv[t.level];
     int sp;
     const u8* im = level_ptr(g, l0, l0pitch, pyr, frame, t.level, &sp);
-    const int SW = BL_TW + 8;
-    for (int i = tid; i < (BL_TH + 6) * (BL_TW + 6); i += 256) {
-        const int yy = i / (BL_TW + 6), xx = i - yy * (BL_TW + 6);
-        const int sy = reflect101(t.y0 + yy - 3, L.h), sx = reflect101(t.x0 + xx - 3, L.w);
-        src[yy * SW + xx] = im[(size_t)sy * sp + sx];
-    }
-    __syncthreads();
-    for (int i = tid; i < (BL_TH + 6) * BL_TW; i += 256) {
-        const int yy = i / BL_TW, xx = i - yy * BL_TW;
-        const u8* s = src + yy * SW + xx;
-        hb[i] = (u16)(18 * (s[0] + s[6]) + 34 * (s[1] + s[5]) + 48 * (s[2] + s[4]) + 56 * s[3]);
-    }
-    __syncthreads();
     u8* dst = blr + (size_t)frame * g.pyrFrameBytes + L.off;
-    for (int i = tid; i < BL_TH * BL_TW; i += 256) {
-        const int yy = i / BL_TW, xx = i - yy * BL_TW;
-        const int ox = t.x0 + xx, oy = t.y0 + yy;
-        if (ox < L.w && oy < L.h) {
-            const u16* h = hb + yy * BL_TW + xx;
-            const u32 acc = 18u * (h[0] + h[6 * BL_TW]) + 34u * (h[BL_TW] + h[5 * BL_TW]) +
-                            48u * (h[2 * BL_TW] + h[4 * BL_TW]) + 56u * h[3 * BL_TW];
-            dst[(size_t)oy * L.pitch + ox] = (u8)((acc + 32768u) >> 16);
+    const int w = L.w, h = L.h;
+    const int gl = (w - 1) >> 2;                           // last dword column holding image pixels
+    const int gc = t.g0 + lane;
+    const u32 selB = bs.selB[t.level], selC = bs.selC[t.level];
+    const u32 K1 = 18u | (34u << 8) | (48u << 16) | (56u << 24), K2 = 48u | (34u << 8) | (18u << 16);
+    const int nrows = min(BL_R, h - t.y0) + 6;
+    int hw[7][4];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { hw[k][0] = hw[k][1] = hw[k][2] = hw[k][3] = 0; }
+    // software pipeline: the loads of row group n+1 are issued BEFORE the arithmetic and stores of group n, so
+    // waiting for them never waits for younger stores (vmcnt retires in issue order on gfx9)
+    u32 Bn[7], Xn[7];
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int r = r0 + k;
+            Bn[k] = 0; Xn[k] = 0;
+            if (r < nrows) {
+                const int ys = reflect101(t.y0 - 3 + r, h);
+                const u32* row = (const u32*)(im + (size_t)ys * sp);
+                if (gc <= gl) Bn[k] = gload32(row + gc);
+                const int xg = lane == 0 ? gc - 1 : gc + 1;     // lane 0 fetches its left neighbour, lane 63 its right one
+                if ((lane == 0 || lane == 63) && xg >= 0 && xg <= gl) Xn[k] = gload32(row + xg);
+            }
+        }
+    };
+    fetch(0);
+    for (int r0 = 0; r0 < nrows; r0 += 7) {
+        u32 Bq[7], Xq[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { Bq[k] = Bn[k]; Xq[k] = Xn[k]; }
+        fetch(r0 + 7);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int r = r0 + k;
+            if (r < nrows) {
+                const u32 B = Bq[k], xtra = Xq[k];
+                u32 A = __shfl_up(B, 1);
+                if (lane == 0) A = xtra;
+                const u32 Bf = gc == gl ? __builtin_amdgcn_perm(A, B, selB) : B;
+                u32 C = __shfl_down(Bf, 1);
+                if (lane == 63) C = gc + 1 == gl ? __builtin_amdgcn_perm(B, xtra, selB) : xtra;
+                if (gc == gl) C = __builtin_amdgcn_perm(A, B, selC);
+                if (gc == 0) A = __builtin_amdgcn_perm(C, Bf, 0x01020304u);       // pixels -4..-1 <- 4,3,2,1
+                const u32 w1[4] = {__builtin_amdgcn_alignbyte(Bf, A, 1), __builtin_amdgcn_alignbyte(Bf, A, 2),
+                                   __builtin_amdgcn_alignbyte(Bf, A, 3), Bf};
+                const u32 w2[4] = {__builtin_amdgcn_alignbyte(C, Bf, 1), __builtin_amdgcn_alignbyte(C, Bf, 2),
+                                   __builtin_amdgcn_alignbyte(C, Bf, 3), C};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    hw[k][i] = (int)__builtin_amdgcn_udot4(w2[i], K2, __builtin_amdgcn_udot4(w1[i], K1, 0u, false), false);
+                if (r >= 6) {
+                    u32 packed = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32 acc = 18u * (u32)(hw[(k + 1) % 7][i] + hw[k][i]) + 34u * (u32)(hw[(k + 2) % 7][i] + hw[(k + 6) % 7][i]) +
+                                        48u * (u32)(hw[(k + 3) % 7][i] + hw[(k + 5) % 7][i]) + 56u * (u32)hw[(k + 4) % 7][i] + 32768u;
+                        packed |= (acc >> 16) << (8 * i);
+                    }
+                    if (gc <= gl) *(u32*)(dst + (size_t)(t.y0 + r - 6) * L.pitch + gc * 4) = packed;
+                }
+            }
         }
     }
 }
