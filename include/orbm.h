@@ -50,6 +50,86 @@ int orbm_knn2_batch_async(orbm_t*, const uint8_t* q, int q_stride, const int32_t
                           int32_t* idx2, int32_t* dist2);
 int orbm_last_timing(orbm_t*, float* ms);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Flattened Frame / KeyFrame views.  The reference's searches walk Frame/KeyFrame/MapPoint object graphs; the C++
+ * facade copies the few fields each search reads into these plain arrays.  All pointers below are
+ * HOST pointers; every search uploads them, runs the data-parallel phase (grid gather + 256-bit Hamming) on the
+ * GPU and replays the reference's order-dependent bookkeeping on the host with the device-computed distances.
+ * ------------------------------------------------------------------------------------------------------------ */
+#define ORBM_GRID_COLS 64     /* Frame.h:37 */
+#define ORBM_GRID_ROWS 48     /* Frame.h:38 */
+
+typedef struct { float x, y, size, angle, response; int32_t octave, class_id; } orbm_kp_t;   /* == cv::KeyPoint */
+
+typedef struct {
+    int32_t n;                 /* N keypoints */
+    const orbm_kp_t* kps;      /* mvKeysUn (Frame.h) */
+    const uint8_t* desc;       /* mDescriptors rows */
+    const float* uright;       /* mvuRight or NULL */
+    float min_x, min_y, inv_w, inv_h;   /* mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv */
+    const int32_t* grid_start; /* [64*48+1] CSR, cell = ix*48+iy == mGrid[ix][iy] */
+    const int32_t* grid_idx;   /* keypoint indices in insertion order */
+} orbm_frame_t;
+
+/* M14  Frame::AssignFeaturesToGrid + PosInGrid (Frame.cc:446-480, 883-899) on the GPU.
+ * grid_start[3073], grid_idx[n] are host outputs; returns the number of keypoints placed. */
+int orbm_grid_build(orbm_t*, const orbm_kp_t* kps, int n, float min_x, float min_y, float inv_w, float inv_h,
+                    int32_t* grid_start, int32_t* grid_idx);
+
+/* M14  Frame::GetFeaturesInArea (Frame.cc:784-871) for a batch of windows, with the Hamming distance of every
+ * returned keypoint to the window's query descriptor.  Candidates come out in the reference's order
+ * (ix, iy, insertion).  q_* arrays have nq entries; er_max < 0 disables the stereo gate
+ * (`uright[i] > 0 && fabs(ur - uright[i]) > er_max` -> skipped, ORBmatcher.cc:107-117, 2569-2576).
+ * out_idx/out_dist: [nq][cap]; out_cnt[nq].  Returns 0, or ORBM_E_CAPACITY if any window overflowed `cap`. */
+int orbm_window_candidates(orbm_t*, const orbm_frame_t* f, int nq, const float* qx, const float* qy, const float* qr,
+                           const int32_t* min_level, const int32_t* max_level, const float* q_ur, const float* q_er_max,
+                           const uint8_t* qdesc, int cap, int32_t* out_cnt, int32_t* out_idx, int32_t* out_dist);
+
+/* M4  ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono) (ORBmatcher.cc:2469-2711),
+ * mono / rectified-stereo path.  Per last-frame feature i: valid[i] (MapPoint present, not an outlier, invzc >= 0,
+ * projection inside the image: decided by the caller's camera model), projection (u,v), invzc, octave, angle,
+ * MapPoint descriptor, mp_obs[i] = pMP->Observations() > 0.  cur_blocked[i2] = Cur.mvpMapPoints[i2] already holds a
+ * MapPoint with observations.  match[i2] = index of the last-frame feature whose MapPoint lands on i2, or -1. */
+int orbm_search_by_projection_frame(orbm_t*, const orbm_frame_t* cur, const uint8_t* cur_blocked, const float* scale_factors,
+                                    int nq, const uint8_t* valid, const float* u, const float* v, const float* invzc,
+                                    const int32_t* octave, const float* angle, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                    float th, int forward, int backward, float mbf, int check_ori, int32_t* match);
+
+/* M3  ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) (ORBmatcher.cc:45-239), left camera */
+int orbm_search_by_projection_points(orbm_t*, const orbm_frame_t* f, const uint8_t* blocked, const float* scale_factors,
+                                     int nq, const uint8_t* in_view, const float* px, const float* py, const float* pxr,
+                                     const float* view_cos, const int32_t* level, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                     float th, float nnratio, int32_t* match);
+
+/* M9  ORBmatcher::SearchForInitialization (ORBmatcher.cc:799-943); prev_matched_xy is updated in place */
+int orbm_search_for_initialization(orbm_t*, const orbm_frame_t* f1, const orbm_frame_t* f2, float* prev_matched_xy,
+                                   int window, float nnratio, int check_ori, int32_t* matches12);
+
+/* M10 ORBmatcher::SearchForTriangulation_ (ORBmatcher.cc:1388-1629), pinhole cameras.  FeatureVectors are CSR:
+ * `nodes` ascending, start[nn+1], idx[].  F12: row-major 3x3 (what Pinhole::epipolarConstrain_ builds,
+ * Pinhole.cpp:273-280); (epx,epy) the epipole in image 2 (ORBmatcher.cc:1399-1400). */
+int orbm_search_for_triangulation(orbm_t*, int n1, const orbm_kp_t* kps1, const uint8_t* desc1, const uint8_t* has_mp1, const float* uright1,
+                                  int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
+                                  int n2, const orbm_kp_t* kps2, const uint8_t* desc2, const uint8_t* has_mp2, const float* uright2,
+                                  int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2,
+                                  const float* F12, float epx, float epy, const float* scale_factors2, const float* level_sigma2_2,
+                                  int only_stereo, int coarse, int check_ori, int32_t* matches12);
+
+/* M7  ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (ORBmatcher.cc:314-547), Nleft == -1.  f_match[iF] = KF index or -1 */
+int orbm_search_by_bow(orbm_t*, int nkf, const orbm_kp_t* kps_kf, const uint8_t* desc_kf, const uint8_t* kf_good,
+                       int nnk, const int32_t* nodes_k, const int32_t* start_k, const int32_t* idx_k,
+                       int nf, const orbm_kp_t* kps_f, const uint8_t* desc_f,
+                       int nnf, const int32_t* nodes_f, const int32_t* start_f, const int32_t* idx_f,
+                       float nnratio, int check_ori, int32_t* f_match);
+
+/* M15 Frame::ComputeStereoMatches (Frame.cc:1027-1276).  left/right are orbx_t* extractor handles (include/orbx.h)
+ * on the same device whose LAST call produced the two keypoint sets: their device-resident pyramids supply the
+ * 11x11 SAD windows (mvImagePyramid, include/ORBextractor.h:83).  frame_l/frame_r select the batch slot.
+ * uright/depth: host outputs [nl] (mvuRight, mvDepth).  Returns the number of stereo points kept. */
+int orbm_stereo_matches(orbm_t*, void* left_extractor, int frame_l, void* right_extractor, int frame_r,
+                        int nl, const orbm_kp_t* kl, const uint8_t* dl, int nr, const orbm_kp_t* kr, const uint8_t* dr,
+                        float mb, float mbf, float* uright, float* depth);
+
 #ifdef __cplusplus
 }
 #endif

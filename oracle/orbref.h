@@ -63,6 +63,66 @@ void orbref_three_maxima(const int* hist_counts, int L, int* ind3);      /* ORBm
 /* brute-force 2-NN (Frame.cc:1440-1480 / cv::BFMatcher knnMatch k=2); ties -> lower train index */
 void orbref_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx2, int32_t* dist2);
 
+
+/* ---- flattened Frame view used by the matcher restatements (Frame.h:37-38 grid 64x48, Frame.cc:446-480) ---- */
+#define ORBREF_GRID_COLS 64
+#define ORBREF_GRID_ROWS 48
+typedef struct {
+    int32_t n;                 /* N keypoints */
+    const orbref_kp_t* kps;    /* mvKeysUn (== mvKeys when undistortion is the identity) */
+    const uint8_t* desc;       /* mDescriptors, n x 32 */
+    const float* uright;       /* mvuRight or NULL */
+    float min_x, min_y, inv_w, inv_h;   /* mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv */
+    const int32_t* grid_start; /* [64*48+1] CSR over cells, cell = ix*48+iy (mGrid[ix][iy]) */
+    const int32_t* grid_idx;   /* keypoint indices, insertion order inside a cell */
+} orbref_frame_t;
+
+/* Frame::AssignFeaturesToGrid + PosInGrid (Frame.cc:446-480, 883-899); returns #keypoints placed */
+int orbref_grid_build(const orbref_kp_t* kps, int n, float min_x, float min_y, float inv_w, float inv_h,
+                      int32_t* grid_start, int32_t* grid_idx);
+/* Frame::GetFeaturesInArea (Frame.cc:784-871) */
+int orbref_features_in_area(const orbref_frame_t* f, float x, float y, float r, int min_level, int max_level,
+                            int32_t* out, int cap);
+
+/* ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) (ORBmatcher.cc:2469-2711), left/mono path.
+ * Per last-frame feature i (nq of them): valid[i] = has MapPoint && !outlier && invzc>=0 && projection inside
+ * the image bounds (all decided by the caller's camera model), (u,v) the projection, invzc, octave, angle, the
+ * MapPoint descriptor and mp_obs[i] = (pMP->Observations()>0).  cur_blocked[i2] = CurrentFrame.mvpMapPoints[i2]
+ * already holds a MapPoint with observations.  Output match[i2] = i or -1. */
+int orbref_search_by_projection_frame(const orbref_frame_t* cur, const uint8_t* cur_blocked, const float* scale_factors,
+                                      int nq, const uint8_t* valid, const float* u, const float* v, const float* invzc,
+                                      const int32_t* octave, const float* angle, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                      float th, int forward, int backward, float mbf, int check_ori, int32_t* match);
+/* ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th, ...) (ORBmatcher.cc:45-239), left path.
+ * Per MapPoint: in_view, proj x/y/xr, view cos, predicted level, descriptor, obs flag. */
+int orbref_search_by_projection_points(const orbref_frame_t* f, const uint8_t* blocked, const float* scale_factors,
+                                       int nq, const uint8_t* in_view, const float* px, const float* py, const float* pxr,
+                                       const float* view_cos, const int32_t* level, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                       float th, float nnratio, int32_t* match);
+/* ORBmatcher::SearchForInitialization (ORBmatcher.cc:799-943) */
+int orbref_search_for_initialization(const orbref_frame_t* f1, const orbref_frame_t* f2, float* prev_matched_xy,
+                                     int window, float nnratio, int check_ori, int32_t* matches12);
+/* ORBmatcher::SearchForTriangulation_ (ORBmatcher.cc:1388-1629), pinhole / no second camera.
+ * FeatureVectors flattened as CSR: nodes sorted ascending, per node a list of feature indices.
+ * F12 = the 3x3 fundamental matrix epipolarConstrain_ builds (Pinhole.cpp:273-296), row-major. */
+int orbref_search_for_triangulation(int n1, const orbref_kp_t* kps1, const uint8_t* desc1, const uint8_t* has_mp1, const float* uright1,
+                                    int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
+                                    int n2, const orbref_kp_t* kps2, const uint8_t* desc2, const uint8_t* has_mp2, const float* uright2,
+                                    int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2,
+                                    const float* F12, float epx, float epy, const float* scale_factors2, const float* level_sigma2_2,
+                                    int only_stereo, int coarse, int check_ori, int32_t* matches12);
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (ORBmatcher.cc:314-547), Nleft == -1 path.
+ * kf_good[i] = KF feature i has a MapPoint that is not bad.  Output f_match[iF] = KF feature index or -1. */
+int orbref_search_by_bow(int nkf, const orbref_kp_t* kps_kf, const uint8_t* desc_kf, const uint8_t* kf_good,
+                         int nnk, const int32_t* nodes_k, const int32_t* start_k, const int32_t* idx_k,
+                         int nf, const orbref_kp_t* kps_f, const uint8_t* desc_f,
+                         int nnf, const int32_t* nodes_f, const int32_t* start_f, const int32_t* idx_f,
+                         float nnratio, int check_ori, int32_t* f_match);
+/* Frame::ComputeStereoMatches (Frame.cc:1027-1276).  Pyramids are those of the two extractors' last call. */
+int orbref_stereo_matches(const orbref_t* left, const orbref_t* right,
+                          int nl, const orbref_kp_t* kl, const uint8_t* dl, int nr, const orbref_kp_t* kr, const uint8_t* dr,
+                          float mb, float mbf, float* uright, float* depth);
+
 #ifdef __cplusplus
 }
 #endif

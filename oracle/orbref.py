@@ -183,3 +183,37 @@ def knn2(q, t):
     idx = np.zeros((q.shape[0], 2), np.int32); dist = np.zeros((q.shape[0], 2), np.int32)
     lib().orbref_knn2(_p(q), q.shape[0], _p(t), t.shape[0], _p(idx), _p(dist))
     return idx, dist
+
+
+# ---- matcher restatements on flattened arrays (same argument lists as the product's ORBmatcher) ----
+def _oracle_matcher_class():
+    import importlib
+    pkg = importlib.import_module("orb-slam3_amd")
+    L = lib()
+    pkg._bind_search(L, "orbref_")
+    L.orbref_features_in_area.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.orbref_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+
+    class OracleMatcher(pkg._SearchMixin):
+        _prefix = "orbref_"
+
+        def __init__(self):
+            self.L = L
+            self.h = None
+
+        def features_in_area(self, f, x, y, r, min_level, max_level):
+            out = np.zeros(max(f.n, 1), np.int32)
+            cs = f.cstruct()
+            n = L.orbref_features_in_area(C.byref(cs), float(x), float(y), float(r), int(min_level), int(max_level), _p(out), out.shape[0])
+            return out[:n]
+
+        def ComputeStereoMatches(self, ex_left, ex_right, kl, dl, kr, dr, mb, mbf):
+            kl = np.ascontiguousarray(kl); kr = np.ascontiguousarray(kr)
+            dl = np.ascontiguousarray(dl, np.uint8); dr = np.ascontiguousarray(dr, np.uint8)
+            ur = np.zeros(max(len(kl), 1), np.float32); dp = np.zeros(max(len(kl), 1), np.float32)
+            n = L.orbref_stereo_matches(ex_left.h, ex_right.h, len(kl), _p(kl), _p(dl), len(kr), _p(kr), _p(dr),
+                                        float(mb), float(mbf), _p(ur), _p(dp))
+            return n, ur[:len(kl)], dp[:len(kl)]
+
+    return OracleMatcher

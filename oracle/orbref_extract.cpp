@@ -672,3 +672,11 @@ int orbref_distribute(const int32_t* xyr, int n, int minX, int maxX, int minY, i
 const int8_t* orbref_pattern(void) { return kPattern; }
 
 }  // extern "C"
+
+// internal accessor for the stereo restatement (orbref_frame.cpp): level image of the last extract call
+extern "C" const uint8_t* orbref_level_data(const orbref_t* o, int level, int* w, int* h) {
+    if (!o || level < 0 || level >= o->nlevels) return nullptr;
+    *w = o->pyr[level].w; *h = o->pyr[level].h;
+    return o->pyr[level].d.data();
+}
+extern "C" int orbref_nlevels(const orbref_t* o) { return o->nlevels; }

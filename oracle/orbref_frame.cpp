@@ -1,0 +1,437 @@
+// orbref_frame.cpp -- CPU ORACLE for the Frame grid / ORBmatcher searches on flattened arrays
+// (TEST INFRASTRUCTURE ONLY, see orbref.h).  Each function keeps the reference's loop structure:
+// GetFeaturesInArea -> DescriptorDistance -> best/second bookkeeping -> rotation histogram.
+// PARITY UNPINNED (no golden vectors in the reference).  Built with -ffp-contract=off.
+#include "orbref.h"
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+extern "C" const uint8_t* orbref_level_data(const orbref_t* o, int level, int* w, int* h);
+extern "C" int orbref_nlevels(const orbref_t* o);
+
+namespace {
+const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;     // ORBmatcher.cc:36-38
+const int GC = ORBREF_GRID_COLS, GR = ORBREF_GRID_ROWS;
+
+void features_in_area(const orbref_frame_t* f, float x, float y, float r, int minLevel, int maxLevel, std::vector<int>& out) {
+    out.clear();                                               // Frame.cc:784-871
+    const float factorX = r, factorY = r;
+    const int nMinCellX = std::max(0, (int)std::floor((x - f->min_x - factorX) * f->inv_w));
+    if (nMinCellX >= GC) return;
+    const int nMaxCellX = std::min(GC - 1, (int)std::ceil((x - f->min_x + factorX) * f->inv_w));
+    if (nMaxCellX < 0) return;
+    const int nMinCellY = std::max(0, (int)std::floor((y - f->min_y - factorY) * f->inv_h));
+    if (nMinCellY >= GR) return;
+    const int nMaxCellY = std::min(GR - 1, (int)std::ceil((y - f->min_y + factorY) * f->inv_h));
+    if (nMaxCellY < 0) return;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const int c = ix * GR + iy;
+            for (int j = f->grid_start[c]; j < f->grid_start[c + 1]; ++j) {
+                const int k = f->grid_idx[j];
+                const orbref_kp_t& kp = f->kps[k];
+                if (bCheckLevels) {
+                    if (kp.octave < minLevel) continue;
+                    if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                }
+                const float distx = kp.x - x, disty = kp.y - y;
+                if (std::fabs(distx) < factorX && std::fabs(disty) < factorY) out.push_back(k);
+            }
+        }
+}
+
+struct RotHist {
+    std::vector<int> bins[HISTO_LENGTH];
+    void add(float a1, float a2, float factor, int idx) {
+        float rot = a1 - a2;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        bins[bin].push_back(idx);
+    }
+    void maxima(int* ind) const {
+        int sz[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; ++i) sz[i] = (int)bins[i].size();
+        orbref_three_maxima(sz, HISTO_LENGTH, ind);
+    }
+};
+}  // namespace
+
+extern "C" {
+
+int orbref_grid_build(const orbref_kp_t* kps, int n, float min_x, float min_y, float inv_w, float inv_h,
+                      int32_t* grid_start, int32_t* grid_idx) {
+    std::vector<std::vector<int>> cells((size_t)GC * GR);
+    int placed = 0;
+    for (int i = 0; i < n; ++i) {
+        const int posX = (int)std::round((kps[i].x - min_x) * inv_w);       // Frame.cc:888-889 (round, not floor)
+        const int posY = (int)std::round((kps[i].y - min_y) * inv_h);
+        if (posX < 0 || posX >= GC || posY < 0 || posY >= GR) continue;
+        cells[(size_t)posX * GR + posY].push_back(i);
+        ++placed;
+    }
+    int o = 0;
+    for (int c = 0; c < GC * GR; ++c) {
+        grid_start[c] = o;
+        for (int k : cells[c]) grid_idx[o++] = k;
+    }
+    grid_start[GC * GR] = o;
+    return placed;
+}
+
+int orbref_features_in_area(const orbref_frame_t* f, float x, float y, float r, int min_level, int max_level, int32_t* out, int cap) {
+    std::vector<int> v;
+    features_in_area(f, x, y, r, min_level, max_level, v);
+    for (size_t i = 0; i < v.size() && (int)i < cap; ++i) out[i] = v[i];
+    return (int)v.size();
+}
+
+int orbref_search_by_projection_frame(const orbref_frame_t* cur, const uint8_t* cur_blocked, const float* sf,
+                                      int nq, const uint8_t* valid, const float* u, const float* v, const float* invzc,
+                                      const int32_t* octave, const float* angle, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                      float th, int bForward, int bBackward, float mbf, int check_ori, int32_t* match) {
+    int nmatches = 0;
+    RotHist rh;
+    const float factor = HISTO_LENGTH / 360.0f;                               // ORBmatcher.cc:2480
+    std::vector<uint8_t> blocked(cur_blocked, cur_blocked + cur->n);
+    for (int i = 0; i < cur->n; ++i) match[i] = -1;
+    std::vector<int> vIndices2;
+    for (int i = 0; i < nq; ++i) {
+        if (!valid[i]) continue;
+        const int nLastOctave = octave[i];
+        const float radius = th * sf[nLastOctave];
+        if (bForward) features_in_area(cur, u[i], v[i], radius, nLastOctave, -1, vIndices2);
+        else if (bBackward) features_in_area(cur, u[i], v[i], radius, 0, nLastOctave, vIndices2);
+        else features_in_area(cur, u[i], v[i], radius, nLastOctave - 1, nLastOctave + 1, vIndices2);
+        if (vIndices2.empty()) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            if (blocked[i2]) continue;                                        // :2565-2567
+            if (cur->uright && cur->uright[i2] > 0) {                         // :2569-2576
+                const float ur = u[i] - mbf * invzc[i];
+                const float er = std::fabs(ur - cur->uright[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = orbref_hamming(qdesc + 32 * (size_t)i, cur->desc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (match[bestIdx2] < 0) {} // (re-assignment of an unblocked slot simply overwrites, as in the reference)
+            match[bestIdx2] = i;
+            if (mp_obs[i]) blocked[bestIdx2] = 1;
+            nmatches++;
+            if (check_ori) rh.add(angle[i], cur->kps[bestIdx2].angle, factor, bestIdx2);
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int b = 0; b < HISTO_LENGTH; ++b)
+            if (b != ind[0] && b != ind[1] && b != ind[2])
+                for (int idx : rh.bins[b]) { match[idx] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
+int orbref_search_by_projection_points(const orbref_frame_t* f, const uint8_t* blocked_in, const float* sf,
+                                       int nq, const uint8_t* in_view, const float* px, const float* py, const float* pxr,
+                                       const float* view_cos, const int32_t* level, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                       float th, float nnratio, int32_t* match) {
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    std::vector<uint8_t> blocked(blocked_in, blocked_in + f->n);
+    for (int i = 0; i < f->n; ++i) match[i] = -1;
+    std::vector<int> vIndices;
+    for (int iMP = 0; iMP < nq; ++iMP) {
+        if (!in_view[iMP]) continue;
+        const int nPredictedLevel = level[iMP];
+        float r = view_cos[iMP] > 0.998 ? 2.5f : 4.0f;                        // RadiusByViewingCos :242-249
+        if (bFactor) r *= th;
+        features_in_area(f, px[iMP], py[iMP], r * sf[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel, vIndices);
+        if (vIndices.empty()) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int idx : vIndices) {
+            if (blocked[idx]) continue;
+            if (f->uright && f->uright[idx] > 0) {
+                const float er = std::fabs(pxr[iMP] - f->uright[idx]);
+                if (er > r * sf[nPredictedLevel]) continue;
+            }
+            const int dist = orbref_hamming(qdesc + 32 * (size_t)iMP, f->desc + 32 * (size_t)idx);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = f->kps[idx].octave; bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = f->kps[idx].octave; bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                match[bestIdx] = iMP;
+                if (mp_obs[iMP]) blocked[bestIdx] = 1;
+                nmatches++;
+            }
+        }
+    }
+    return nmatches;
+}
+
+int orbref_search_for_initialization(const orbref_frame_t* F1, const orbref_frame_t* F2, float* prev, int windowSize,
+                                     float nnratio, int check_ori, int32_t* vnMatches12) {
+    int nmatches = 0;
+    for (int i = 0; i < F1->n; ++i) vnMatches12[i] = -1;
+    RotHist rh;
+    const float factor = HISTO_LENGTH / 360.0f;                               // :812
+    std::vector<int> vMatchedDistance(F2->n, INT_MAX), vnMatches21(F2->n, -1), vIndices2;
+    for (int i1 = 0; i1 < F1->n; ++i1) {
+        const int level1 = F1->kps[i1].octave;
+        if (level1 > 0) continue;
+        features_in_area(F2, prev[2 * i1], prev[2 * i1 + 1], (float)windowSize, level1, level1, vIndices2);
+        if (vIndices2.empty()) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            const int dist = orbref_hamming(F1->desc + 32 * (size_t)i1, F2->desc + 32 * (size_t)i2);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                vnMatches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_ori) rh.add(F1->kps[i1].angle, F2->kps[bestIdx2].angle, factor, i1);
+            }
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int b = 0; b < HISTO_LENGTH; ++b) {
+            if (b == ind[0] || b == ind[1] || b == ind[2]) continue;
+            for (int idx1 : rh.bins[b])
+                if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+        }
+    }
+    for (int i1 = 0; i1 < F1->n; ++i1)
+        if (vnMatches12[i1] >= 0) { prev[2 * i1] = F2->kps[vnMatches12[i1]].x; prev[2 * i1 + 1] = F2->kps[vnMatches12[i1]].y; }
+    return nmatches;
+}
+
+static bool epipolar_constrain(const float* F12, const orbref_kp_t& kp1, const orbref_kp_t& kp2, float unc) {
+    // Pinhole::epipolarConstrain_ (Pinhole.cpp:281-295) with F12 precomputed by the caller
+    const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+    const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+    const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+    const float num = a * kp2.x + b * kp2.y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * unc;
+}
+
+int orbref_search_for_triangulation(int n1, const orbref_kp_t* kps1, const uint8_t* desc1, const uint8_t* has_mp1, const float* uright1,
+                                    int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1v,
+                                    int n2, const orbref_kp_t* kps2, const uint8_t* desc2, const uint8_t* has_mp2, const float* uright2,
+                                    int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2v,
+                                    const float* F12, float epx, float epy, const float* sf2, const float* sigma2_2,
+                                    int bOnlyStereo, int bCoarse, int check_ori, int32_t* vMatches12) {
+    int nmatches = 0;
+    std::vector<bool> vbMatched2(n2, false);                                  // never set in this overload (:1567)
+    for (int i = 0; i < n1; ++i) vMatches12[i] = -1;
+    RotHist rh;
+    const float factor = 1.0f / HISTO_LENGTH;                                 // :1441 (sic)
+    int a = 0, b = 0;
+    while (a < nn1 && b < nn2) {
+        if (nodes1[a] == nodes2[b]) {
+            for (int i1 = start1[a]; i1 < start1[a + 1]; ++i1) {
+                const int idx1 = idx1v[i1];
+                if (has_mp1[idx1]) continue;
+                const bool bStereo1 = uright1 && uright1[idx1] >= 0;
+                if (bOnlyStereo && !bStereo1) continue;
+                const orbref_kp_t& kp1 = kps1[idx1];
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int i2 = start2[b]; i2 < start2[b + 1]; ++i2) {
+                    const int idx2 = idx2v[i2];
+                    if (vbMatched2[idx2] || has_mp2[idx2]) continue;
+                    const bool bStereo2 = uright2 && uright2[idx2] >= 0;
+                    if (bOnlyStereo && !bStereo2) continue;
+                    const int dist = orbref_hamming(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const orbref_kp_t& kp2 = kps2[idx2];
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = epx - kp2.x, distey = epy - kp2.y;
+                        if (distex * distex + distey * distey < 100 * sf2[kp2.octave]) continue;
+                    }
+                    if (epipolar_constrain(F12, kp1, kp2, sigma2_2[kp2.octave]) || bCoarse) { bestIdx2 = idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    vMatches12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (check_ori) rh.add(kp1.angle, kps2[bestIdx2].angle, factor, idx1);
+                }
+            }
+            ++a; ++b;
+        } else if (nodes1[a] < nodes2[b]) {
+            a = (int)(std::lower_bound(nodes1, nodes1 + nn1, nodes2[b]) - nodes1);
+        } else {
+            b = (int)(std::lower_bound(nodes2, nodes2 + nn2, nodes1[a]) - nodes2);
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int bb = 0; bb < HISTO_LENGTH; ++bb) {
+            if (bb == ind[0] || bb == ind[1] || bb == ind[2]) continue;
+            for (int i : rh.bins[bb]) { vMatches12[i] = -1; nmatches--; }
+        }
+    }
+    (void)n1;
+    return nmatches;
+}
+
+int orbref_search_by_bow(int nkf, const orbref_kp_t* kps_kf, const uint8_t* desc_kf, const uint8_t* kf_good,
+                         int nnk, const int32_t* nodes_k, const int32_t* start_k, const int32_t* idx_k,
+                         int nf, const orbref_kp_t* kps_f, const uint8_t* desc_f,
+                         int nnf, const int32_t* nodes_f, const int32_t* start_f, const int32_t* idx_f,
+                         float nnratio, int check_ori, int32_t* f_match) {
+    for (int i = 0; i < nf; ++i) f_match[i] = -1;
+    int nmatches = 0;
+    RotHist rh;
+    const float factor = HISTO_LENGTH / 360.0f;                               // :334
+    int a = 0, b = 0;
+    while (a < nnk && b < nnf) {
+        if (nodes_k[a] == nodes_f[b]) {
+            for (int iKF = start_k[a]; iKF < start_k[a + 1]; ++iKF) {
+                const int realIdxKF = idx_k[iKF];
+                if (!kf_good[realIdxKF]) continue;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (int iF = start_f[b]; iF < start_f[b + 1]; ++iF) {
+                    const int realIdxF = idx_f[iF];
+                    if (f_match[realIdxF] >= 0) continue;                    // :385
+                    const int dist = orbref_hamming(desc_kf + 32 * (size_t)realIdxKF, desc_f + 32 * (size_t)realIdxF);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 <= TH_LOW) {
+                    if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                        f_match[bestIdxF] = realIdxKF;
+                        if (check_ori) rh.add(kps_kf[realIdxKF].angle, kps_f[bestIdxF].angle, factor, bestIdxF);
+                        nmatches++;
+                    }
+                }
+            }
+            ++a; ++b;
+        } else if (nodes_k[a] < nodes_f[b]) {
+            a = (int)(std::lower_bound(nodes_k, nodes_k + nnk, nodes_f[b]) - nodes_k);
+        } else {
+            b = (int)(std::lower_bound(nodes_f, nodes_f + nnf, nodes_k[a]) - nodes_f);
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int bb = 0; bb < HISTO_LENGTH; ++bb) {
+            if (bb == ind[0] || bb == ind[1] || bb == ind[2]) continue;
+            for (int i : rh.bins[bb]) { f_match[i] = -1; nmatches--; }
+        }
+    }
+    (void)nkf;
+    return nmatches;
+}
+
+int orbref_stereo_matches(const orbref_t* left, const orbref_t* right,
+                          int N, const orbref_kp_t* kl, const uint8_t* dl, int Nr, const orbref_kp_t* kr, const uint8_t* dr,
+                          float mb, float mbf, float* mvuRight, float* mvDepth) {
+    const int L_ = orbref_nlevels(left);
+    std::vector<float> sf(L_), isf(L_);
+    orbref_tables(left, sf.data(), isf.data(), nullptr, nullptr, nullptr, nullptr);
+    for (int i = 0; i < N; ++i) { mvuRight[i] = -1.0f; mvDepth[i] = -1.0f; }
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    int w0, nRows;
+    orbref_level_data(left, 0, &w0, &nRows);
+    std::vector<std::vector<int>> vRowIndices(nRows);
+    for (int iR = 0; iR < Nr; ++iR) {
+        const float kpY = kr[iR].y;
+        const float r = 2.0f * sf[kr[iR].octave];
+        const int maxr = (int)std::ceil(kpY + r), minr = (int)std::floor(kpY - r);
+        for (int yi = minr; yi <= maxr; ++yi)
+            if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR);          // reference indexes unchecked (rows exist for real keypoints)
+    }
+    const float minZ = mb, minD = 0, maxD = mbf / minZ;
+    std::vector<std::pair<int, int>> vDistIdx;
+    for (int iL = 0; iL < N; ++iL) {
+        const orbref_kp_t& kpL = kl[iL];
+        const int levelL = kpL.octave;
+        const float vL = kpL.y, uL = kpL.x;
+        const std::vector<int>& vCandidates = vRowIndices[(int)vL];
+        if (vCandidates.empty()) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = TH_HIGH;
+        int bestIdxR = 0;
+        for (int iR : vCandidates) {
+            const orbref_kp_t& kpR = kr[iR];
+            if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+            const float uR = kpR.x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = orbref_hamming(dl + 32 * (size_t)iL, dr + 32 * (size_t)iR);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        if (bestDist < thOrbDist) {
+            const float uR0 = kr[bestIdxR].x;
+            const float scaleFactor = isf[kpL.octave];
+            const float scaleduL = std::round(kpL.x * scaleFactor), scaledvL = std::round(kpL.y * scaleFactor);
+            const float scaleduR0 = std::round(uR0 * scaleFactor);
+            const int w = 5, Lh = 5;
+            int lw, lh, rw, rh_;
+            const uint8_t* IL = orbref_level_data(left, kpL.octave, &lw, &lh);
+            const uint8_t* IR = orbref_level_data(right, kpL.octave, &rw, &rh_);
+            int bestDistS = INT_MAX, bestincR = 0;
+            float vDists[11];
+            const float iniu = scaleduR0 + Lh - w, endu = scaleduR0 + Lh + w + 1;
+            if (iniu < 0 || endu >= rw) continue;
+            for (int incR = -Lh; incR <= Lh; ++incR) {
+                int sad = 0;
+                for (int dy = -w; dy <= w; ++dy)
+                    for (int dx = -w; dx <= w; ++dx)
+                        sad += std::abs((int)IL[((int)scaledvL + dy) * lw + (int)scaleduL + dx] -
+                                        (int)IR[((int)scaledvL + dy) * rw + (int)scaleduR0 + incR + dx]);
+                const float dist = (float)(double)sad;                         // cv::norm(NORM_L1) -> double -> float
+                if (dist < bestDistS) { bestDistS = (int)dist; bestincR = incR; }
+                vDists[Lh + incR] = dist;
+            }
+            if (bestincR == -Lh || bestincR == Lh) continue;
+            const float dist1 = vDists[Lh + bestincR - 1], dist2 = vDists[Lh + bestincR], dist3 = vDists[Lh + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = sf[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) { disparity = 0.01; bestuR = uL - 0.01; }
+                mvDepth[iL] = mbf / disparity;
+                mvuRight[iL] = bestuR;
+                vDistIdx.push_back(std::pair<int, int>(bestDistS, iL));
+            }
+        }
+    }
+    if (vDistIdx.empty()) return 0;                                            // reference indexes an empty vector here (UB)
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    int kept = (int)vDistIdx.size();
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; --i) {
+        if (vDistIdx[i].first < thDist) break;
+        mvuRight[vDistIdx[i].second] = -1; mvDepth[vDistIdx[i].second] = -1; --kept;
+    }
+    return kept;
+}
+
+}  // extern "C"

@@ -328,3 +328,185 @@ class ORBmatcher:
         t = C.c_float()
         _chk(self.L.orbm_last_timing(self.h, C.byref(t)), "orbm_last_timing")
         return t.value
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Flattened Frame / KeyFrame views for the searches (include/orbm.h).  FrameView mirrors the members of
+# ORB_SLAM3::Frame the matcher reads: mvKeysUn, mDescriptors, mvuRight, mGrid + bounds (include/Frame.h).
+# ---------------------------------------------------------------------------------------------------------------
+GRID_COLS, GRID_ROWS = 64, 48
+
+
+class _CFrame(C.Structure):
+    _fields_ = [("n", C.c_int32), ("kps", C.c_void_p), ("desc", C.c_void_p), ("uright", C.c_void_p),
+                ("min_x", C.c_float), ("min_y", C.c_float), ("inv_w", C.c_float), ("inv_h", C.c_float),
+                ("grid_start", C.c_void_p), ("grid_idx", C.c_void_p)]
+
+
+def _bind_search(L, prefix):
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    g = lambda n: getattr(L, prefix + n)
+    h = [vp] if prefix == "orbm_" else []
+    g("grid_build").argtypes = h + [vp, ci, cf, cf, cf, cf, vp, vp]
+    g("search_by_projection_frame").argtypes = h + [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, cf, ci, vp]
+    g("search_by_projection_points").argtypes = h + [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, vp]
+    g("search_for_initialization").argtypes = h + [vp, vp, vp, ci, cf, ci, vp]
+    g("search_for_triangulation").argtypes = h + [ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp, vp,
+                                                  vp, cf, cf, vp, vp, ci, ci, ci, vp]
+    g("search_by_bow").argtypes = h + [ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, cf, ci, vp]
+
+
+class FrameView:
+    """Plain-array view of a Frame; `backend` is an object exposing grid_build (ORBmatcher here, the oracle in tests)."""
+
+    def __init__(self, kps, desc, width, height, uright=None, backend=None):
+        self.kps = np.ascontiguousarray(kps); self.desc = np.ascontiguousarray(desc, np.uint8)
+        self.n = len(self.kps)
+        self.uright = None if uright is None else np.ascontiguousarray(uright, np.float32)
+        # undistortion-free bounds (Frame::ComputeImageBounds with k1 == 0, Frame.cc:1005-1021)
+        self.min_x, self.min_y = np.float32(0), np.float32(0)
+        self.inv_w = np.float32(GRID_COLS) / (np.float32(width) - self.min_x)
+        self.inv_h = np.float32(GRID_ROWS) / (np.float32(height) - self.min_y)
+        self.grid_start = np.zeros(GRID_COLS * GRID_ROWS + 1, np.int32)
+        self.grid_idx = np.zeros(max(self.n, 1), np.int32)
+        if backend is not None:
+            backend.grid_build(self)
+
+    def cstruct(self):
+        return _CFrame(self.n, self.kps.ctypes.data, self.desc.ctypes.data,
+                       None if self.uright is None else self.uright.ctypes.data,
+                       float(self.min_x), float(self.min_y), float(self.inv_w), float(self.inv_h),
+                       self.grid_start.ctypes.data, self.grid_idx.ctypes.data)
+
+
+def feature_vector_csr(node_of_feature):
+    """DBoW2::FeatureVector (map<NodeId, vector<unsigned>>) as CSR: nodes ascending, features ascending inside."""
+    node_of_feature = np.asarray(node_of_feature, np.int64)
+    order = np.argsort(node_of_feature, kind="stable").astype(np.int32)
+    nodes, counts = np.unique(node_of_feature, return_counts=True)
+    start = np.zeros(len(nodes) + 1, np.int32); start[1:] = np.cumsum(counts)
+    return nodes.astype(np.int32), start, order
+
+
+class _SearchMixin:
+    """Search entry points shared by the product matcher and (in tests) the oracle wrapper: same argument lists."""
+    _prefix = "orbm_"
+
+    def _call(self, name, *args):
+        f = getattr(self.L, self._prefix + name)
+        a = ([self.h] if self._prefix == "orbm_" else []) + list(args)
+        rc = f(*a)
+        if rc < 0 and self._prefix == "orbm_":
+            _chk(rc, name)
+        return rc
+
+    def grid_build(self, fv):
+        fv.placed = self._call("grid_build", _p(fv.kps), fv.n, float(fv.min_x), float(fv.min_y), float(fv.inv_w), float(fv.inv_h),
+                                _p(fv.grid_start), _p(fv.grid_idx))
+        return fv.placed
+
+    def SearchByProjectionFrame(self, cur, cur_blocked, scale_factors, valid, u, v, invzc, octave, angle, qdesc, mp_obs,
+                                th, forward=False, backward=False, mbf=0.0, check_ori=True):
+        match = np.full(cur.n, -1, np.int32)
+        cs = cur.cstruct()
+        arr = [np.ascontiguousarray(a, t) for a, t in ((cur_blocked, np.uint8), (scale_factors, np.float32), (valid, np.uint8),
+               (u, np.float32), (v, np.float32), (invzc, np.float32), (octave, np.int32), (angle, np.float32),
+               (qdesc, np.uint8), (mp_obs, np.uint8))]
+        n = self._call("search_by_projection_frame", C.byref(cs), _p(arr[0]), _p(arr[1]), len(arr[2]), *[_p(a) for a in arr[2:]],
+                       float(th), int(forward), int(backward), float(mbf), int(check_ori), _p(match))
+        return n, match
+
+    def SearchByProjectionPoints(self, f, blocked, scale_factors, in_view, px, py, pxr, view_cos, level, qdesc, mp_obs, th, nnratio):
+        match = np.full(f.n, -1, np.int32)
+        cs = f.cstruct()
+        arr = [np.ascontiguousarray(a, t) for a, t in ((blocked, np.uint8), (scale_factors, np.float32), (in_view, np.uint8),
+               (px, np.float32), (py, np.float32), (pxr, np.float32), (view_cos, np.float32), (level, np.int32),
+               (qdesc, np.uint8), (mp_obs, np.uint8))]
+        n = self._call("search_by_projection_points", C.byref(cs), _p(arr[0]), _p(arr[1]), len(arr[2]), *[_p(a) for a in arr[2:]],
+                       float(th), float(nnratio), _p(match))
+        return n, match
+
+    def SearchForInitialization(self, f1, f2, prev_matched, window, nnratio, check_ori=True):
+        prev = np.ascontiguousarray(prev_matched, np.float32).copy()
+        m12 = np.full(f1.n, -1, np.int32)
+        c1, c2 = f1.cstruct(), f2.cstruct()
+        n = self._call("search_for_initialization", C.byref(c1), C.byref(c2), _p(prev), int(window), float(nnratio), int(check_ori), _p(m12))
+        return n, m12, prev
+
+    def SearchForTriangulation(self, k1, d1, has_mp1, ur1, fv1, k2, d2, has_mp2, ur2, fv2, F12, ep, sf2, sigma2_2,
+                               only_stereo=False, coarse=False, check_ori=False):
+        m12 = np.full(len(k1), -1, np.int32)
+        k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)
+        d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        h1 = np.ascontiguousarray(has_mp1, np.uint8); h2 = np.ascontiguousarray(has_mp2, np.uint8)
+        u1 = None if ur1 is None else np.ascontiguousarray(ur1, np.float32)
+        u2 = None if ur2 is None else np.ascontiguousarray(ur2, np.float32)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9); sf2 = np.ascontiguousarray(sf2, np.float32)
+        sg = np.ascontiguousarray(sigma2_2, np.float32)
+        n = self._call("search_for_triangulation", len(k1), _p(k1), _p(d1), _p(h1), None if u1 is None else _p(u1),
+                       len(fv1[0]), _p(fv1[0]), _p(fv1[1]), _p(fv1[2]),
+                       len(k2), _p(k2), _p(d2), _p(h2), None if u2 is None else _p(u2),
+                       len(fv2[0]), _p(fv2[0]), _p(fv2[1]), _p(fv2[2]),
+                       _p(F), float(ep[0]), float(ep[1]), _p(sf2), _p(sg), int(only_stereo), int(coarse), int(check_ori), _p(m12))
+        return n, m12
+
+    def SearchByBoW(self, kkf, dkf, kf_good, fvk, kf_, df, fvf, nnratio, check_ori=True):
+        fm = np.full(len(kf_), -1, np.int32)
+        kkf = np.ascontiguousarray(kkf); kf_ = np.ascontiguousarray(kf_)
+        dkf = np.ascontiguousarray(dkf, np.uint8); df = np.ascontiguousarray(df, np.uint8)
+        good = np.ascontiguousarray(kf_good, np.uint8)
+        n = self._call("search_by_bow", len(kkf), _p(kkf), _p(dkf), _p(good), len(fvk[0]), _p(fvk[0]), _p(fvk[1]), _p(fvk[2]),
+                       len(kf_), _p(kf_), _p(df), len(fvf[0]), _p(fvf[0]), _p(fvf[1]), _p(fvf[2]),
+                       float(nnratio), int(check_ori), _p(fm))
+        return n, fm
+
+
+def _install_search():
+    L = lib()
+    _bind_search(L, "orbm_")
+    L.orbm_window_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int] + [C.c_void_p] * 3
+    L.orbm_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    for name in ("grid_build", "SearchByProjectionFrame", "SearchByProjectionPoints", "SearchForInitialization",
+                 "SearchForTriangulation", "SearchByBoW", "_call"):
+        setattr(ORBmatcher, name, getattr(_SearchMixin, name))
+    ORBmatcher._prefix = "orbm_"
+
+    def window_candidates(self, f, qx, qy, qr, min_level, max_level, qdesc, cap, q_ur=None, q_er=None):
+        nq = len(qx)
+        arr = [np.ascontiguousarray(a, t) for a, t in ((qx, np.float32), (qy, np.float32), (qr, np.float32),
+               (min_level, np.int32), (max_level, np.int32))]
+        ur = None if q_ur is None else np.ascontiguousarray(q_ur, np.float32)
+        er = None if q_er is None else np.ascontiguousarray(q_er, np.float32)
+        qd = np.ascontiguousarray(qdesc, np.uint8)
+        cnt = np.zeros(nq, np.int32); idx = np.zeros((nq, cap), np.int32); dist = np.zeros((nq, cap), np.int32)
+        cs = f.cstruct()
+        _chk(self.L.orbm_window_candidates(self.h, C.byref(cs), nq, *[_p(a) for a in arr], None if ur is None else _p(ur),
+                                           None if er is None else _p(er), _p(qd), cap, _p(cnt), _p(idx), _p(dist)), "window_candidates")
+        return cnt, idx, dist
+
+    def stereo_matches(self, ex_left, ex_right, kl, dl, kr, dr, mb, mbf, frame_l=0, frame_r=0):
+        kl = np.ascontiguousarray(kl); kr = np.ascontiguousarray(kr)
+        dl = np.ascontiguousarray(dl, np.uint8); dr = np.ascontiguousarray(dr, np.uint8)
+        ur = np.zeros(max(len(kl), 1), np.float32); dp = np.zeros(max(len(kl), 1), np.float32)
+        n = _chk(self.L.orbm_stereo_matches(self.h, ex_left.h, frame_l, ex_right.h, frame_r, len(kl), _p(kl), _p(dl), len(kr), _p(kr), _p(dr),
+                                            float(mb), float(mbf), _p(ur), _p(dp)), "stereo_matches")
+        return n, ur[:len(kl)], dp[:len(kl)]
+
+    ORBmatcher.window_candidates = window_candidates
+    ORBmatcher.ComputeStereoMatches = stereo_matches
+
+
+EXPORTS += ["orbm_grid_build", "orbm_window_candidates", "orbm_search_by_projection_frame", "orbm_search_by_projection_points",
+            "orbm_search_for_initialization", "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_stereo_matches"]
+_orig_lib = lib
+_search_ready = False
+
+
+def lib():                                         # noqa: F811  (binds the search entry points on first use)
+    global _search_ready
+    L = _orig_lib()
+    if not _search_ready:
+        _search_ready = True
+        _install_search()
+    return L

@@ -5,8 +5,12 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
+#include <climits>
+#include <cmath>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace orbmk;
@@ -134,6 +138,459 @@ int orbm_last_timing(orbm_t* m, float* ms) {
     MHIPCHK(hipStreamSynchronize(m->stream));
     MHIPCHK(hipEventElapsedTime(ms, m->e0, m->e1));
     return ORBM_OK;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// Flattened searches: GPU distance phase + host replay of the reference's sequential bookkeeping
+// =================================================================================================
+extern "C" int orbx_internal_levels(void* o, int frame, int* nlevels, const uint8_t** ptr, int* pitch, int* w, int* h,
+                                    float* sf, float* isf, int* device);
+
+namespace {
+
+struct DevBuf {                                              // RAII device allocation + upload helpers
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4) == hipSuccess; }
+    bool upload(const void* src, size_t bytes) { return alloc(bytes) && (bytes == 0 || hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) == hipSuccess); }
+    template <class T> T* as() { return (T*)p; }
+};
+#define UP(buf, src, bytes) do { if (!(buf).upload((src), (bytes))) { set_merr("device upload failed (%zu B)", (size_t)(bytes)); return ORBM_E_HIP; } } while (0)
+#define AL(buf, bytes) do { if (!(buf).alloc((bytes))) { set_merr("device allocation failed (%zu B)", (size_t)(bytes)); return ORBM_E_HIP; } } while (0)
+
+struct RotHist {                                             // rotation-consistency histogram (e.g. ORBmatcher.cc:459-466)
+    std::vector<int> bins[ORBM_HISTO_LENGTH];
+    void add(float a1, float a2, float factor, int idx) {
+        float rot = a1 - a2;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == ORBM_HISTO_LENGTH) bin = 0;
+        if (bin >= 0 && bin < ORBM_HISTO_LENGTH) bins[bin].push_back(idx);
+    }
+    void maxima(int* ind) const {
+        int sz[ORBM_HISTO_LENGTH];
+        for (int i = 0; i < ORBM_HISTO_LENGTH; ++i) sz[i] = (int)bins[i].size();
+        orbm_three_maxima(sz, ORBM_HISTO_LENGTH, ind);
+    }
+};
+
+// runs k_window for nq windows against frame f; candidate lists come back in host vectors
+int window_pass(orbm* m, const orbm_frame_t* f, int nq, const float* qx, const float* qy, const float* qr,
+                const int32_t* minl, const int32_t* maxl, const float* qur, const float* qer, const uint8_t* qdesc,
+                int cap, std::vector<int>& cnt, std::vector<int>& idx, std::vector<int>& dist) {
+    cnt.assign(nq, 0);
+    if (nq == 0 || f->n == 0) return ORBM_OK;
+    MHIPCHK(hipSetDevice(m->device));
+    DevBuf dk, dd, du, dgs, dgi, dqx, dqy, dqr, dmin, dmax, dqu, dqe, dqd, dcnt, didx, ddist, dovf;
+    UP(dk, f->kps, sizeof(KpIn) * f->n); UP(dd, f->desc, (size_t)32 * f->n);
+    if (f->uright) UP(du, f->uright, sizeof(float) * f->n);
+    UP(dgs, f->grid_start, sizeof(int) * (ORBM_GRID_COLS * ORBM_GRID_ROWS + 1));
+    UP(dgi, f->grid_idx, sizeof(int) * f->n);
+    UP(dqx, qx, sizeof(float) * nq); UP(dqy, qy, sizeof(float) * nq); UP(dqr, qr, sizeof(float) * nq);
+    UP(dmin, minl, sizeof(int) * nq); UP(dmax, maxl, sizeof(int) * nq);
+    if (qur) UP(dqu, qur, sizeof(float) * nq);
+    if (qer) UP(dqe, qer, sizeof(float) * nq);
+    UP(dqd, qdesc, (size_t)32 * nq);
+    AL(dcnt, sizeof(int) * nq); AL(didx, sizeof(int) * (size_t)nq * cap); AL(ddist, sizeof(int) * (size_t)nq * cap); AL(dovf, sizeof(int));
+    MHIPCHK(hipMemsetAsync(dovf.p, 0, sizeof(int), m->stream));
+    MHIPCHK(hipEventRecord(m->e0, m->stream));
+    hipLaunchKernelGGL(k_window, dim3((nq + 3) / 4), dim3(256), 0, m->stream, dk.as<KpIn>(), dd.as<uint8_t>(),
+                       f->uright ? du.as<float>() : nullptr, dgs.as<int>(), dgi.as<int>(), f->min_x, f->min_y, f->inv_w, f->inv_h,
+                       nq, dqx.as<float>(), dqy.as<float>(), dqr.as<float>(), dmin.as<int>(), dmax.as<int>(),
+                       qur ? dqu.as<float>() : nullptr, qer ? dqe.as<float>() : nullptr, dqd.as<uint8_t>(), cap,
+                       dcnt.as<int>(), didx.as<int>(), ddist.as<int>(), dovf.as<int>());
+    MHIPCHK(hipEventRecord(m->e1, m->stream));
+    m->timed = true;
+    MHIPCHK(hipGetLastError());
+    MHIPCHK(hipStreamSynchronize(m->stream));
+    int ovf = 0;
+    MHIPCHK(hipMemcpy(&ovf, dovf.p, sizeof(int), hipMemcpyDeviceToHost));
+    idx.resize((size_t)nq * cap); dist.resize((size_t)nq * cap);
+    MHIPCHK(hipMemcpy(cnt.data(), dcnt.p, sizeof(int) * nq, hipMemcpyDeviceToHost));
+    MHIPCHK(hipMemcpy(idx.data(), didx.p, sizeof(int) * (size_t)nq * cap, hipMemcpyDeviceToHost));
+    MHIPCHK(hipMemcpy(dist.data(), ddist.p, sizeof(int) * (size_t)nq * cap, hipMemcpyDeviceToHost));
+    if (ovf) { set_merr("a search window returned more than %d candidates", cap); return ORBM_E_CAPACITY; }
+    return ORBM_OK;
+}
+
+// merge-join of two FeatureVector CSRs (ORBmatcher.cc:343-518 / 1448-1595) -> jobs + GPU distances
+struct JoinJobs { std::vector<int> q, l2, len, off, node_b; int total = 0; };
+
+int bucket_pass(orbm* m, const uint8_t* d1, int n1, const uint8_t* d2, int n2, const int32_t* idx2, int nidx2,
+                const JoinJobs& J, std::vector<int>& dist) {
+    dist.assign(J.total, 0);
+    if (J.total == 0) return ORBM_OK;
+    MHIPCHK(hipSetDevice(m->device));
+    DevBuf b1, b2, bi, bq, bl, bo, bout;
+    UP(b1, d1, (size_t)32 * n1); UP(b2, d2, (size_t)32 * n2); UP(bi, idx2, sizeof(int) * nidx2);
+    const int nj = (int)J.q.size();
+    UP(bq, J.q.data(), sizeof(int) * nj); UP(bl, J.l2.data(), sizeof(int) * nj); UP(bo, J.off.data(), sizeof(int) * nj);
+    AL(bout, sizeof(int) * (size_t)J.total);
+    MHIPCHK(hipEventRecord(m->e0, m->stream));
+    hipLaunchKernelGGL(k_pairdist, dim3((J.total + 255) / 256), dim3(256), 0, m->stream, b1.as<uint8_t>(), b2.as<uint8_t>(),
+                       bi.as<int>(), nj, bq.as<int>(), bl.as<int>(), bo.as<int>(), J.total, bout.as<int>());
+    MHIPCHK(hipEventRecord(m->e1, m->stream));
+    m->timed = true;
+    MHIPCHK(hipGetLastError());
+    MHIPCHK(hipStreamSynchronize(m->stream));
+    MHIPCHK(hipMemcpy(dist.data(), bout.p, sizeof(int) * (size_t)J.total, hipMemcpyDeviceToHost));
+    return ORBM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbm_grid_build(orbm_t* m, const orbm_kp_t* kps, int n, float min_x, float min_y, float inv_w, float inv_h,
+                    int32_t* grid_start, int32_t* grid_idx) {
+    if (!m || !grid_start || !grid_idx || n < 0 || (n > 0 && !kps)) return ORBM_E_INVALID;
+    if (n > 65535) { set_merr("grid build supports at most 65535 keypoints"); return ORBM_E_CAPACITY; }
+    MHIPCHK(hipSetDevice(m->device));
+    int n2 = 64; while (n2 < n) n2 <<= 1;
+    if ((size_t)n2 * 4 > 150 * 1024) { set_merr("too many keypoints for the LDS sort"); return ORBM_E_CAPACITY; }
+    DevBuf dk, dgs, dgi, dpl;
+    UP(dk, kps, sizeof(KpIn) * n);
+    AL(dgs, sizeof(int) * (ORBM_GRID_COLS * ORBM_GRID_ROWS + 1)); AL(dgi, sizeof(int) * (n + 1)); AL(dpl, sizeof(int));
+    MHIPCHK(hipFuncSetAttribute((const void*)k_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 4));
+    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), (size_t)n2 * 4, m->stream, dk.as<KpIn>(), n, n2, min_x, min_y, inv_w, inv_h,
+                       dgs.as<int>(), dgi.as<int>(), dpl.as<int>());
+    MHIPCHK(hipGetLastError());
+    MHIPCHK(hipStreamSynchronize(m->stream));
+    int placed = 0;
+    MHIPCHK(hipMemcpy(&placed, dpl.p, sizeof(int), hipMemcpyDeviceToHost));
+    MHIPCHK(hipMemcpy(grid_start, dgs.p, sizeof(int) * (ORBM_GRID_COLS * ORBM_GRID_ROWS + 1), hipMemcpyDeviceToHost));
+    if (placed) MHIPCHK(hipMemcpy(grid_idx, dgi.p, sizeof(int) * placed, hipMemcpyDeviceToHost));
+    return placed;
+}
+
+int orbm_window_candidates(orbm_t* m, const orbm_frame_t* f, int nq, const float* qx, const float* qy, const float* qr,
+                           const int32_t* min_level, const int32_t* max_level, const float* q_ur, const float* q_er_max,
+                           const uint8_t* qdesc, int cap, int32_t* out_cnt, int32_t* out_idx, int32_t* out_dist) {
+    if (!m || !f || nq < 0 || cap < 1) return ORBM_E_INVALID;
+    std::vector<int> cnt, idx, dist;
+    int rc = window_pass(m, f, nq, qx, qy, qr, min_level, max_level, q_ur, q_er_max, qdesc, cap, cnt, idx, dist);
+    if (rc && rc != ORBM_E_CAPACITY) return rc;
+    for (int i = 0; i < nq; ++i) out_cnt[i] = cnt[i];
+    if (!idx.empty()) { memcpy(out_idx, idx.data(), idx.size() * sizeof(int)); memcpy(out_dist, dist.data(), dist.size() * sizeof(int)); }
+    return rc;
+}
+
+int orbm_search_by_projection_frame(orbm_t* m, const orbm_frame_t* cur, const uint8_t* cur_blocked, const float* sf,
+                                    int nq, const uint8_t* valid, const float* u, const float* v, const float* invzc,
+                                    const int32_t* octave, const float* angle, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                    float th, int bForward, int bBackward, float mbf, int check_ori, int32_t* match) {
+    if (!m || !cur || nq < 0) return ORBM_E_INVALID;
+    // windows exactly as ORBmatcher.cc:2543-2549; invalid queries get an empty window (r < 0)
+    std::vector<float> qr(nq), qur(nq), qer(nq);
+    std::vector<int> minl(nq), maxl(nq);
+    for (int i = 0; i < nq; ++i) {
+        if (!valid[i]) { qr[i] = -1.f; minl[i] = 0; maxl[i] = -1; qur[i] = 0; qer[i] = -1.f; continue; }
+        const int o = octave[i];
+        const float radius = th * sf[o];
+        qr[i] = radius;
+        if (bForward) { minl[i] = o; maxl[i] = -1; }
+        else if (bBackward) { minl[i] = 0; maxl[i] = o; }
+        else { minl[i] = o - 1; maxl[i] = o + 1; }
+        qur[i] = u[i] - mbf * invzc[i];                                    // :2571
+        qer[i] = cur->uright ? radius : -1.f;
+    }
+    const int cap = std::max(1, std::min(cur->n, 2048));
+    std::vector<int> cnt, idx, dist;
+    int rc = window_pass(m, cur, nq, u, v, qr.data(), minl.data(), maxl.data(), qur.data(), qer.data(), qdesc, cap, cnt, idx, dist);
+    if (rc) return rc;
+    // sequential replay of the claims (ORBmatcher.cc:2553-2612)
+    int nmatches = 0;
+    RotHist rh;
+    const float factor = ORBM_HISTO_LENGTH / 360.0f;
+    std::vector<uint8_t> blocked(cur_blocked, cur_blocked + cur->n);
+    for (int i = 0; i < cur->n; ++i) match[i] = -1;
+    for (int i = 0; i < nq; ++i) {
+        if (!valid[i] || cnt[i] == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < cnt[i]; ++c) {
+            const int i2 = idx[(size_t)i * cap + c];
+            if (blocked[i2]) continue;
+            const int d = dist[(size_t)i * cap + c];
+            if (d < bestDist) { bestDist = d; bestIdx2 = i2; }
+        }
+        if (bestDist <= ORBM_TH_HIGH) {
+            match[bestIdx2] = i;
+            if (mp_obs[i]) blocked[bestIdx2] = 1;
+            nmatches++;
+            if (check_ori) rh.add(angle[i], cur->kps[bestIdx2].angle, factor, bestIdx2);
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int b = 0; b < ORBM_HISTO_LENGTH; ++b)
+            if (b != ind[0] && b != ind[1] && b != ind[2])
+                for (int k : rh.bins[b]) { match[k] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
+int orbm_search_by_projection_points(orbm_t* m, const orbm_frame_t* f, const uint8_t* blocked_in, const float* sf,
+                                     int nq, const uint8_t* in_view, const float* px, const float* py, const float* pxr,
+                                     const float* view_cos, const int32_t* level, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                     float th, float nnratio, int32_t* match) {
+    if (!m || !f || nq < 0) return ORBM_E_INVALID;
+    const bool bFactor = th != 1.0;
+    std::vector<float> qr(nq), qer(nq);
+    std::vector<int> minl(nq), maxl(nq);
+    for (int i = 0; i < nq; ++i) {
+        if (!in_view[i]) { qr[i] = -1.f; minl[i] = 0; maxl[i] = -1; qer[i] = -1.f; continue; }
+        float r = view_cos[i] > 0.998 ? 2.5f : 4.0f;                       // RadiusByViewingCos (:242-249)
+        if (bFactor) r *= th;
+        qr[i] = r * sf[level[i]];
+        minl[i] = level[i] - 1; maxl[i] = level[i];
+        qer[i] = f->uright ? r * sf[level[i]] : -1.f;                      // :107-117
+    }
+    const int cap = std::max(1, std::min(f->n, 2048));
+    std::vector<int> cnt, idx, dist;
+    int rc = window_pass(m, f, nq, px, py, qr.data(), minl.data(), maxl.data(), pxr, qer.data(), qdesc, cap, cnt, idx, dist);
+    if (rc) return rc;
+    int nmatches = 0;
+    std::vector<uint8_t> blocked(blocked_in, blocked_in + f->n);
+    for (int i = 0; i < f->n; ++i) match[i] = -1;
+    for (int iMP = 0; iMP < nq; ++iMP) {
+        if (!in_view[iMP] || cnt[iMP] == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = 0; c < cnt[iMP]; ++c) {
+            const int k = idx[(size_t)iMP * cap + c];
+            if (blocked[k]) continue;
+            const int d = dist[(size_t)iMP * cap + c];
+            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = f->kps[k].octave; bestIdx = k; }
+            else if (d < bestDist2) { bestLevel2 = f->kps[k].octave; bestDist2 = d; }
+        }
+        if (bestDist <= ORBM_TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                match[bestIdx] = iMP;
+                if (mp_obs[iMP]) blocked[bestIdx] = 1;
+                nmatches++;
+            }
+        }
+    }
+    return nmatches;
+}
+
+int orbm_search_for_initialization(orbm_t* m, const orbm_frame_t* F1, const orbm_frame_t* F2, float* prev, int windowSize,
+                                   float nnratio, int check_ori, int32_t* vnMatches12) {
+    if (!m || !F1 || !F2) return ORBM_E_INVALID;
+    const int n1 = F1->n;
+    std::vector<float> qx(n1), qy(n1), qr(n1);
+    std::vector<int> minl(n1), maxl(n1);
+    for (int i = 0; i < n1; ++i) {
+        const int l1 = F1->kps[i].octave;
+        qx[i] = prev[2 * i]; qy[i] = prev[2 * i + 1];
+        if (l1 > 0) { qr[i] = -1.f; minl[i] = 0; maxl[i] = -1; }           // :825
+        else { qr[i] = (float)windowSize; minl[i] = l1; maxl[i] = l1; }
+    }
+    const int cap = std::max(1, std::min(F2->n, 4096));
+    std::vector<int> cnt, idx, dist;
+    int rc = window_pass(m, F2, n1, qx.data(), qy.data(), qr.data(), minl.data(), maxl.data(), nullptr, nullptr, F1->desc, cap, cnt, idx, dist);
+    if (rc) return rc;
+    int nmatches = 0;
+    for (int i = 0; i < n1; ++i) vnMatches12[i] = -1;
+    RotHist rh;
+    const float factor = ORBM_HISTO_LENGTH / 360.0f;
+    std::vector<int> vMatchedDistance(F2->n, INT_MAX), vnMatches21(F2->n, -1);
+    for (int i1 = 0; i1 < n1; ++i1) {
+        if (F1->kps[i1].octave > 0 || cnt[i1] == 0) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int c = 0; c < cnt[i1]; ++c) {
+            const int i2 = idx[(size_t)i1 * cap + c], d = dist[(size_t)i1 * cap + c];
+            if (vMatchedDistance[i2] <= d) continue;
+            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestIdx2 = i2; }
+            else if (d < bestDist2) bestDist2 = d;
+        }
+        if (bestDist <= ORBM_TH_LOW && bestDist < (float)bestDist2 * nnratio) {
+            if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+            vnMatches12[i1] = bestIdx2; vnMatches21[bestIdx2] = i1; vMatchedDistance[bestIdx2] = bestDist;
+            nmatches++;
+            if (check_ori) rh.add(F1->kps[i1].angle, F2->kps[bestIdx2].angle, factor, i1);
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int b = 0; b < ORBM_HISTO_LENGTH; ++b) {
+            if (b == ind[0] || b == ind[1] || b == ind[2]) continue;
+            for (int i1 : rh.bins[b]) if (vnMatches12[i1] >= 0) { vnMatches12[i1] = -1; nmatches--; }
+        }
+    }
+    for (int i1 = 0; i1 < n1; ++i1)
+        if (vnMatches12[i1] >= 0) { prev[2 * i1] = F2->kps[vnMatches12[i1]].x; prev[2 * i1 + 1] = F2->kps[vnMatches12[i1]].y; }
+    return nmatches;
+}
+
+static void join_nodes(int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1, int nn2, const int32_t* nodes2,
+                       const int32_t* start2, JoinJobs& J) {
+    int a = 0, b = 0;                                                       // lower_bound jumps == this linear merge on sorted keys
+    while (a < nn1 && b < nn2) {
+        if (nodes1[a] == nodes2[b]) {
+            const int len = start2[b + 1] - start2[b];
+            for (int i = start1[a]; i < start1[a + 1]; ++i) {
+                J.q.push_back(idx1[i]); J.l2.push_back(start2[b]); J.len.push_back(len); J.off.push_back(J.total); J.node_b.push_back(b);
+                J.total += len;
+            }
+            ++a; ++b;
+        } else if (nodes1[a] < nodes2[b]) ++a; else ++b;
+    }
+}
+
+int orbm_search_for_triangulation(orbm_t* m, int n1, const orbm_kp_t* kps1, const uint8_t* desc1, const uint8_t* has_mp1, const float* uright1,
+                                  int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
+                                  int n2, const orbm_kp_t* kps2, const uint8_t* desc2, const uint8_t* has_mp2, const float* uright2,
+                                  int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2,
+                                  const float* F12, float epx, float epy, const float* sf2, const float* sigma2_2,
+                                  int bOnlyStereo, int bCoarse, int check_ori, int32_t* vMatches12) {
+    if (!m || n1 < 0 || n2 < 0) return ORBM_E_INVALID;
+    JoinJobs J;
+    join_nodes(nn1, nodes1, start1, idx1, nn2, nodes2, start2, J);
+    std::vector<int> dist;
+    int rc = bucket_pass(m, desc1, n1, desc2, n2, idx2, start2[nn2], J, dist);
+    if (rc) return rc;
+    for (int i = 0; i < n1; ++i) vMatches12[i] = -1;
+    int nmatches = 0;
+    RotHist rh;
+    const float factor = 1.0f / ORBM_HISTO_LENGTH;                          // :1441 (sic)
+    for (size_t j = 0; j < J.q.size(); ++j) {
+        const int i1 = J.q[j];
+        if (has_mp1[i1]) continue;
+        const bool bStereo1 = uright1 && uright1[i1] >= 0;
+        if (bOnlyStereo && !bStereo1) continue;
+        const orbm_kp_t& kp1 = kps1[i1];
+        int bestDist = ORBM_TH_LOW, bestIdx2 = -1;
+        for (int c = 0; c < J.len[j]; ++c) {
+            const int i2 = idx2[J.l2[j] + c];
+            if (has_mp2[i2]) continue;
+            const bool bStereo2 = uright2 && uright2[i2] >= 0;
+            if (bOnlyStereo && !bStereo2) continue;
+            const int d = dist[J.off[j] + c];
+            if (d > ORBM_TH_LOW || d > bestDist) continue;
+            const orbm_kp_t& kp2 = kps2[i2];
+            if (!bStereo1 && !bStereo2) {
+                const float distex = epx - kp2.x, distey = epy - kp2.y;
+                if (distex * distex + distey * distey < 100 * sf2[kp2.octave]) continue;
+            }
+            bool epi = false;
+            {   // Pinhole::epipolarConstrain_ (Pinhole.cpp:281-295)
+                const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+                const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+                const float c2 = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+                const float num = a * kp2.x + b * kp2.y + c2;
+                const float den = a * a + b * b;
+                if (den != 0) { const float dsqr = num * num / den; epi = dsqr < 3.84 * sigma2_2[kp2.octave]; }
+            }
+            if (epi || bCoarse) { bestIdx2 = i2; bestDist = d; }
+        }
+        if (bestIdx2 >= 0) {
+            vMatches12[i1] = bestIdx2;
+            nmatches++;
+            if (check_ori) rh.add(kp1.angle, kps2[bestIdx2].angle, factor, i1);
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int b = 0; b < ORBM_HISTO_LENGTH; ++b) {
+            if (b == ind[0] || b == ind[1] || b == ind[2]) continue;
+            for (int i : rh.bins[b]) { vMatches12[i] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+int orbm_search_by_bow(orbm_t* m, int nkf, const orbm_kp_t* kps_kf, const uint8_t* desc_kf, const uint8_t* kf_good,
+                       int nnk, const int32_t* nodes_k, const int32_t* start_k, const int32_t* idx_k,
+                       int nf, const orbm_kp_t* kps_f, const uint8_t* desc_f,
+                       int nnf, const int32_t* nodes_f, const int32_t* start_f, const int32_t* idx_f,
+                       float nnratio, int check_ori, int32_t* f_match) {
+    if (!m || nkf < 0 || nf < 0) return ORBM_E_INVALID;
+    JoinJobs J;
+    join_nodes(nnk, nodes_k, start_k, idx_k, nnf, nodes_f, start_f, J);
+    std::vector<int> dist;
+    int rc = bucket_pass(m, desc_kf, nkf, desc_f, nf, idx_f, start_f[nnf], J, dist);
+    if (rc) return rc;
+    for (int i = 0; i < nf; ++i) f_match[i] = -1;
+    int nmatches = 0;
+    RotHist rh;
+    const float factor = ORBM_HISTO_LENGTH / 360.0f;                        // :334
+    for (size_t j = 0; j < J.q.size(); ++j) {                              // jobs are in the reference's (node, iKF) order
+        const int iKF = J.q[j];
+        if (!kf_good[iKF]) continue;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        for (int c = 0; c < J.len[j]; ++c) {
+            const int iF = idx_f[J.l2[j] + c];
+            if (f_match[iF] >= 0) continue;                                 // :385 -- order-dependent gate
+            const int d = dist[J.off[j] + c];
+            if (d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdxF = iF; }
+            else if (d < bestDist2) bestDist2 = d;
+        }
+        if (bestDist1 <= ORBM_TH_LOW && static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+            f_match[bestIdxF] = iKF;
+            if (check_ori) rh.add(kps_kf[iKF].angle, kps_f[bestIdxF].angle, factor, bestIdxF);
+            nmatches++;
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int b = 0; b < ORBM_HISTO_LENGTH; ++b) {
+            if (b == ind[0] || b == ind[1] || b == ind[2]) continue;
+            for (int i : rh.bins[b]) { f_match[i] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+int orbm_stereo_matches(orbm_t* m, void* left, int frame_l, void* right, int frame_r,
+                        int nl, const orbm_kp_t* kl, const uint8_t* dl, int nr, const orbm_kp_t* kr, const uint8_t* dr,
+                        float mb, float mbf, float* uright, float* depth) {
+    if (!m || !left || !right || nl < 0 || nr < 0 || nr > 65535) return ORBM_E_INVALID;
+    for (int i = 0; i < nl; ++i) { uright[i] = -1.0f; depth[i] = -1.0f; }
+    if (nl == 0 || nr == 0) return 0;
+    StereoLevels lv;
+    memset(&lv, 0, sizeof lv);
+    int nlev = 0, nlevR = 0, devL = 0, devR = 0, wl[12], hl[12], hr[12];
+    float sfR[12], isfR[12];
+    if (orbx_internal_levels(left, frame_l, &nlev, lv.L, lv.pitchL, wl, hl, lv.sf, lv.isf, &devL) ||
+        orbx_internal_levels(right, frame_r, &nlevR, lv.R, lv.pitchR, lv.wR, hr, sfR, isfR, &devR)) {
+        set_merr("extractor handles hold no pyramid for the requested batch slot"); return ORBM_E_INVALID;
+    }
+    if (nlev != nlevR || devL != m->device || devR != m->device) { set_merr("extractors and matcher must share one device and level count"); return ORBM_E_INVALID; }
+    MHIPCHK(hipSetDevice(m->device));
+    DevBuf bkl, bdl, bkr, bdr, bur, bde, bsad;
+    UP(bkl, kl, sizeof(KpIn) * nl); UP(bdl, dl, (size_t)32 * nl); UP(bkr, kr, sizeof(KpIn) * nr); UP(bdr, dr, (size_t)32 * nr);
+    AL(bur, sizeof(float) * nl); AL(bde, sizeof(float) * nl); AL(bsad, sizeof(int) * nl);
+    MHIPCHK(hipEventRecord(m->e0, m->stream));
+    hipLaunchKernelGGL(k_stereo, dim3((nl + 3) / 4), dim3(256), 0, m->stream, bkl.as<KpIn>(), bdl.as<uint8_t>(), nl, bkr.as<KpIn>(),
+                       bdr.as<uint8_t>(), nr, lv, mb, mbf, bur.as<float>(), bde.as<float>(), bsad.as<int>());
+    MHIPCHK(hipEventRecord(m->e1, m->stream));
+    m->timed = true;
+    MHIPCHK(hipGetLastError());
+    MHIPCHK(hipStreamSynchronize(m->stream));
+    std::vector<int> sad(nl);
+    MHIPCHK(hipMemcpy(uright, bur.p, sizeof(float) * nl, hipMemcpyDeviceToHost));
+    MHIPCHK(hipMemcpy(depth, bde.p, sizeof(float) * nl, hipMemcpyDeviceToHost));
+    MHIPCHK(hipMemcpy(sad.data(), bsad.p, sizeof(int) * nl, hipMemcpyDeviceToHost));
+    // median cut (Frame.cc:1261-1275)
+    std::vector<std::pair<int, int>> vDistIdx;
+    for (int i = 0; i < nl; ++i) if (sad[i] >= 0) vDistIdx.push_back(std::make_pair(sad[i], i));
+    if (vDistIdx.empty()) return 0;
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    int kept = (int)vDistIdx.size();
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; --i) {
+        if (vDistIdx[i].first < thDist) break;
+        uright[vDistIdx[i].second] = -1; depth[vDistIdx[i].second] = -1; --kept;
+    }
+    return kept;
 }
 
 }  // extern "C"

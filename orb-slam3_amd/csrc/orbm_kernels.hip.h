@@ -70,4 +70,251 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_grid_build: Frame::AssignFeaturesToGrid (Frame.cc:446-480).  One workgroup per frame.
+// Stable order inside a cell = ascending keypoint index: sort keys (cell<<16 | index) with a bitonic
+// sort in LDS, then every cell finds its start with a binary search.
+// ------------------------------------------------------------------------------------------------
+struct KpIn { float x, y, size, angle, response; int octave, class_id; };
+
+__global__ __launch_bounds__(256) void k_grid_build(const KpIn* __restrict__ kps, int n, int n2, float min_x, float min_y,
+                                                    float inv_w, float inv_h, int* __restrict__ grid_start,
+                                                    int* __restrict__ grid_idx, int* __restrict__ placed) {
+    extern __shared__ unsigned int keys[];
+    const int tid = threadIdx.x;
+    __shared__ int s_placed;
+    if (tid == 0) s_placed = 0;
+    __syncthreads();
+    for (int i = tid; i < n2; i += 256) {
+        unsigned int key = 0xFFFFFFFFu;
+        if (i < n) {
+            const int px = (int)roundf((kps[i].x - min_x) * inv_w);          // PosInGrid: round, not floor (Frame.cc:888-889)
+            const int py = (int)roundf((kps[i].y - min_y) * inv_h);
+            if (px >= 0 && px < 64 && py >= 0 && py < 48) { key = ((unsigned)(px * 48 + py) << 16) | (unsigned)i; atomicAdd(&s_placed, 1); }
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned int a = keys[i], b = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    const int np = s_placed;
+    for (int i = tid; i < np; i += 256) grid_idx[i] = (int)(keys[i] & 0xFFFFu);
+    for (int c = tid; c <= 64 * 48; c += 256) {
+        const unsigned int target = (unsigned)c << 16;
+        int lo = 0, hi = np;                                                  // first key >= target
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < target) lo = mid + 1; else hi = mid; }
+        grid_start[c] = lo;
+    }
+    if (tid == 0) *placed = np;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_window: Frame::GetFeaturesInArea (Frame.cc:784-871) + DescriptorDistance for a batch of windows.
+// One wavefront per window.  Cells of one grid column are contiguous in the CSR (cell = ix*48+iy), so for every
+// ix the lanes sweep ONE index range in the reference's visiting order; survivors are compacted with a ballot
+// (order preserved) and their 256-bit Hamming distance to the window's descriptor is taken on the spot.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_window(const KpIn* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                const float* __restrict__ uright, const int* __restrict__ gs,
+                                                const int* __restrict__ gi, float min_x, float min_y, float inv_w, float inv_h,
+                                                int nq, const float* __restrict__ qx, const float* __restrict__ qy,
+                                                const float* __restrict__ qr, const int* __restrict__ qminl,
+                                                const int* __restrict__ qmaxl, const float* __restrict__ qur,
+                                                const float* __restrict__ qer, const uint8_t* __restrict__ qdesc, int cap,
+                                                int* __restrict__ out_cnt, int* __restrict__ out_idx, int* __restrict__ out_dist,
+                                                int* __restrict__ overflow) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const float x = qx[q], y = qy[q], r = qr[q];
+    const int minLevel = qminl[q], maxLevel = qmaxl[q];
+    int cnt = 0;
+    const int nMinCellX = max(0, (int)floorf((x - min_x - r) * inv_w));
+    const int nMaxCellX = min(63, (int)ceilf((x - min_x + r) * inv_w));
+    const int nMinCellY = max(0, (int)floorf((y - min_y - r) * inv_h));
+    const int nMaxCellY = min(47, (int)ceilf((y - min_y + r) * inv_h));
+    if (r >= 0 && nMinCellX < 64 && nMaxCellX >= 0 && nMinCellY < 48 && nMaxCellY >= 0) {
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        const uint4* qp = (const uint4*)(qdesc + (size_t)q * 32);
+        const uint4 qlo = qp[0], qhi = qp[1];
+        const u64 a[4] = {(u64)qlo.x | ((u64)qlo.y << 32), (u64)qlo.z | ((u64)qlo.w << 32),
+                          (u64)qhi.x | ((u64)qhi.y << 32), (u64)qhi.z | ((u64)qhi.w << 32)};
+        const float er = qer ? qer[q] : -1.f, ur = qur ? qur[q] : 0.f;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int ix = nMinCellX; ix <= nMaxCellX; ++ix) {
+            const int j0 = gs[ix * 48 + nMinCellY], j1 = gs[ix * 48 + nMaxCellY + 1];
+            for (int jb = j0; jb < j1; jb += 64) {
+                const int j = jb + lane;
+                bool ok = false;
+                int k = 0;
+                if (j < j1) {
+                    k = gi[j];
+                    const KpIn kp = kps[k];
+                    ok = true;
+                    if (bCheckLevels) {
+                        if (kp.octave < minLevel) ok = false;
+                        if (maxLevel >= 0 && kp.octave > maxLevel) ok = false;
+                    }
+                    const float distx = kp.x - x, disty = kp.y - y;
+                    if (!(fabsf(distx) < r && fabsf(disty) < r)) ok = false;
+                    if (ok && er >= 0.f && uright) {
+                        const float urk = uright[k];
+                        if (urk > 0 && fabsf(ur - urk) > er) ok = false;
+                    }
+                }
+                const unsigned long long bal = __ballot(ok);
+                if (ok) {
+                    const int pos = cnt + __popcll(bal & lt);
+                    if (pos < cap) {
+                        const uint4* tp = (const uint4*)(desc + (size_t)k * 32);
+                        const uint4 lo = tp[0], hi = tp[1];
+                        const int d = ham256(a, (u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
+                                             (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32));
+                        out_idx[(size_t)q * cap + pos] = k;
+                        out_dist[(size_t)q * cap + pos] = d;
+                    } else *overflow = 1;
+                }
+                cnt += __popcll(bal);
+            }
+        }
+    }
+    if (lane == 0) out_cnt[q] = min(cnt, cap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pairdist: Hamming distances for a job list (bucket joins of SearchByBoW / SearchForTriangulation_).
+// job j: query row q1[j] of set 1 against rows idx2[l2[j] .. l2[j]+len[j]) of set 2, outputs at off[j]...
+// One thread per output element (the job is found by binary search in the output offsets).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pairdist(const uint8_t* __restrict__ d1, const uint8_t* __restrict__ d2,
+                                                  const int* __restrict__ idx2, int njobs, const int* __restrict__ jq,
+                                                  const int* __restrict__ jl2, const int* __restrict__ joff, int total,
+                                                  int* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    int lo = 0, hi = njobs;                                                   // last job with joff <= e
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (joff[mid] <= e) lo = mid; else hi = mid; }
+    const int k2 = idx2[jl2[lo] + (e - joff[lo])];
+    const uint4* p1 = (const uint4*)(d1 + (size_t)jq[lo] * 32);
+    const uint4* p2 = (const uint4*)(d2 + (size_t)k2 * 32);
+    const uint4 a0 = p1[0], a1 = p1[1], b0 = p2[0], b1 = p2[1];
+    out[e] = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+             __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_stereo: Frame::ComputeStereoMatches (Frame.cc:1027-1256) up to (not including) the median cut.
+// One wavefront per left keypoint.  Candidates = right keypoints whose row band [floor(y-r), ceil(y+r)],
+// r = 2*scale[octave], contains (int)vL (the reference's vRowIndices table, visited in iR order), octave within
+// +-1 and u in [uL-maxD, uL]; best = min (distance, iR).  Then the 11x11 SAD slide over +-5 px on the two
+// un-blurred pyramids, parabola refinement and the disparity gates, all in the reference's float arithmetic.
+// ------------------------------------------------------------------------------------------------
+struct StereoLevels { const uint8_t* L[12]; const uint8_t* R[12]; int pitchL[12], pitchR[12], wR[12]; float sf[12], isf[12]; };
+
+__global__ __launch_bounds__(256) void k_stereo(const KpIn* __restrict__ kl, const uint8_t* __restrict__ dl, int nl,
+                                                const KpIn* __restrict__ kr, const uint8_t* __restrict__ dr, int nr,
+                                                StereoLevels lv, float mb, float mbf, float* __restrict__ uright,
+                                                float* __restrict__ depth, int* __restrict__ bestSad) {
+    const int lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (iL >= nl) return;
+    const KpIn kpL = kl[iL];
+    const int levelL = kpL.octave;
+    const float vL = kpL.y, uL = kpL.x;
+    const int rowL = (int)vL;
+    const float minD = 0, maxD = mbf / mb;
+    const float minU = uL - maxD, maxU = uL - minD;
+    float ur_out = -1.0f, depth_out = -1.0f;
+    int sad_out = -1;
+    if (!(maxU < 0)) {
+        const uint4* qp = (const uint4*)(dl + (size_t)iL * 32);
+        const uint4 qlo = qp[0], qhi = qp[1];
+        const u64 a[4] = {(u64)qlo.x | ((u64)qlo.y << 32), (u64)qlo.z | ((u64)qlo.w << 32),
+                          (u64)qhi.x | ((u64)qhi.y << 32), (u64)qhi.z | ((u64)qhi.w << 32)};
+        unsigned int best = 0xFFFFFFFFu;                                     // (dist << 16) | iR, strict < keeps the first
+        for (int b0 = 0; b0 < nr; b0 += 64) {
+            const int iR = b0 + lane;
+            if (iR < nr) {
+                const KpIn kpR = kr[iR];
+                const float r = 2.0f * lv.sf[kpR.octave];
+                const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
+                if (rowL >= minr && rowL <= maxr && kpR.octave >= levelL - 1 && kpR.octave <= levelL + 1 &&
+                    kpR.x >= minU && kpR.x <= maxU) {
+                    const uint4* tp = (const uint4*)(dr + (size_t)iR * 32);
+                    const uint4 lo = tp[0], hi = tp[1];
+                    const int d = ham256(a, (u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
+                                         (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32));
+                    best = min(best, ((unsigned)d << 16) | (unsigned)iR);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+        const int bestDist = best == 0xFFFFFFFFu ? 100 : (int)(best >> 16);
+        if (best != 0xFFFFFFFFu && bestDist < 100 && bestDist < 75) {        // < TH_HIGH to replace the init, < thOrbDist to go on
+            const int bestIdxR = (int)(best & 0xFFFFu);
+            const float uR0 = kr[bestIdxR].x;
+            const float scaleFactor = lv.isf[levelL];
+            const float scaleduL = roundf(kpL.x * scaleFactor), scaledvL = roundf(kpL.y * scaleFactor);
+            const float scaleduR0 = roundf(uR0 * scaleFactor);
+            const int w = 5, Lh = 5;
+            const float iniu = scaleduR0 + Lh - w, endu = scaleduR0 + Lh + w + 1;
+            if (!(iniu < 0 || endu >= (float)lv.wR[levelL])) {
+                const uint8_t* IL = lv.L[levelL];
+                const uint8_t* IR = lv.R[levelL];
+                const int pl = lv.pitchL[levelL], pr = lv.pitchR[levelL];
+                const int cy = (int)scaledvL, cxl = (int)scaleduL, cxr = (int)scaleduR0;
+                int sad[11];
+#pragma unroll
+                for (int k = 0; k < 11; ++k) sad[k] = 0;
+                for (int p = lane; p < 121; p += 64) {
+                    const int dy = p / 11 - w, dx = p % 11 - w;
+                    const int vl = IL[(size_t)(cy + dy) * pl + cxl + dx];
+                    const uint8_t* rr = IR + (size_t)(cy + dy) * pr + cxr + dx;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) sad[k] += abs(vl - (int)rr[k - Lh]);
+                }
+#pragma unroll
+                for (int k = 0; k < 11; ++k)
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) sad[k] += __shfl_xor(sad[k], o);
+                int bestD = 0x7FFFFFFF, bestinc = 0;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) {
+                    const float dist = (float)sad[k];
+                    if (dist < (float)bestD) { bestD = (int)dist; bestinc = k - Lh; }
+                }
+                if (!(bestinc == -Lh || bestinc == Lh)) {
+                    float d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+                    for (int k = 1; k < 10; ++k) if (k - Lh == bestinc) { d1 = (float)sad[k - 1]; d2 = (float)sad[k]; d3 = (float)sad[k + 1]; }
+                    const float deltaR = (d1 - d3) / (2.0f * (d1 + d3 - 2.0f * d2));
+                    if (!(deltaR < -1 || deltaR > 1)) {
+                        float bestuR = lv.sf[levelL] * ((float)scaleduR0 + (float)bestinc + deltaR);
+                        float disparity = (uL - bestuR);
+                        if (disparity >= minD && disparity < maxD) {
+                            if (disparity <= 0) { disparity = 0.01; bestuR = (float)((double)uL - 0.01); }
+                            depth_out = mbf / disparity;
+                            ur_out = bestuR;
+                            sad_out = bestD;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) { uright[iL] = ur_out; depth[iL] = depth_out; bestSad[iL] = sad_out; }
+}
+
 }  // namespace orbmk

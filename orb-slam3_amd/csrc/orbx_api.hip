@@ -73,7 +73,7 @@ struct orbx {
     unsigned long long* dStamps = nullptr;
     size_t capL0 = 0, capPyr = 0, capCells = 0, capTiles = 0, capXt = 0, capYt = 0, capCandCnt = 0, capCandEnt = 0, capSel = 0;
     int lastBatch = 0;
-    int l0pitch = 0;
+    int l0pitch = 0, lastL0Pitch = 0;
     std::vector<const u8*> hL0Ptr;
     std::vector<int> hLap;
     bool timed = false;
@@ -154,7 +154,7 @@ static int build_geometry(orbx* o, int w, int h) {
             if (Hs > 127) { set_err("FAST cell of %d rows exceeds the strip kernel's 127", Hs); return ORBX_E_UNSUPPORTED; }
             const int xal = (f.x0 - 4) & ~15;
             int n = 0, needed = 0;
-            while (ci + n < (int)o->cells.size() && n < 8) {
+            while (ci + n < (int)o->cells.size() && n < F3_NT / 64) {
                 const CellInfo& c = o->cells[ci + n];
                 if (c.y0 != f.y0) break;
                 const int nd = c.x0 + c.cw - 3 - xal + 8;
@@ -429,6 +429,7 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     HIPCHK(hipMemcpyAsync((void*)o->dL0Ptr, o->hL0Ptr.data(), sizeof(u8*) * nimg, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(o->dLap, o->hLap.data(), sizeof(int) * 2 * nimg, hipMemcpyHostToDevice, st));
 
+    o->lastL0Pitch = l0pitch;
     HIPCHK(hipEventRecord(o->ev[0], st));
     for (int l = 1; l < g.nlevels; ++l) {
         if (o->rzStream[l]) {
@@ -625,6 +626,25 @@ int orbx_debug_stamps(orbx_t* o, unsigned long long* out, int n) {
     HIPCHK(hipStreamSynchronize(o->stream));
     HIPCHK(hipMemcpy(out, o->dStamps, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(o->dStamps, 0, 64 * 8));
+    return ORBX_OK;
+}
+
+// internal (not part of include/orbx.h): device pointers of the pyramid levels of batch slot `frame`, used by the
+// stereo matcher living in the same library (orbm_stereo_matches)
+int orbx_internal_levels(orbx_t* o, int frame, int* nlevels, const uint8_t** ptr, int* pitch, int* w, int* h,
+                         float* sf, float* isf, int* device) {
+    if (!o || frame < 0 || frame >= o->lastBatch) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    HIPCHK(hipStreamSynchronize(o->stream));
+    *nlevels = o->nlevels; *device = o->device;
+    for (int l = 0; l < o->nlevels; ++l) {
+        const LevelDesc& D = o->g.lv[l];
+        if (l == 0) {
+            ptr[0] = o->hL0Ptr[frame];
+            pitch[0] = (ptr[0] >= o->dL0 && ptr[0] < o->dL0 + o->capL0) ? o->l0pitch : o->lastL0Pitch;
+        } else { ptr[l] = o->dPyr + (size_t)frame * o->g.pyrFrameBytes + D.off; pitch[l] = D.pitch; }
+        w[l] = D.w; h[l] = D.h; sf[l] = o->sf[l]; isf[l] = o->invsf[l];
+    }
     return ORBX_OK;
 }
 

@@ -324,7 +324,7 @@ struct StripInfo { short level, ncell, x0, y0, w, h, xal, lp; int cell0; };   //
 //   cell window, compacted again -> row-major rank by counting (queue keys are row-major) -> packed store.
 // No atomics, no bitmap: all counts live in wave-uniform registers.
 // ------------------------------------------------------------------------------------------------
-#define F3_NT 512
+#define F3_NT 256
 __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
                                                  const CellInfo* __restrict__ cells, const StripInfo* __restrict__ strips,
                                                  u32* candCnt, u32* candEnt, int* err, int tileBytes, int qcap) {

@@ -1,0 +1,163 @@
+"""GPU parity of the flattened ORBmatcher searches (GPU distance phase + host replay) vs the CPU oracle's
+reference-structured restatements.  Everything compared is integer / index work -> bit-exact; the stereo outputs
+(uright, depth) are floats produced by the same expression sequence and are compared bit-for-bit as well."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene(pkg, oracle, synth):
+    """Two views (synthetic rectified stereo pair) extracted on the GPU, plus oracle extractors holding the same pyramids."""
+    l, r = synth.gen_stereo_pair(752, 480, 100)
+    exl = pkg.ORBextractor(1200, max_size=(752, 480)); exr = pkg.ORBextractor(1200, max_size=(752, 480))
+    _, kl, dl = exl(l, (0, 0)); _, kr, dr = exr(r, (0, 0))
+    ol, orr = oracle.Extractor(1200), oracle.Extractor(1200)
+    ol(l, (0, 0)); orr(r, (0, 0))
+    OM = oracle._oracle_matcher_class()()
+    m = pkg.ORBmatcher(0.7)
+    return dict(l=l, r=r, exl=exl, exr=exr, kl=kl, dl=dl, kr=kr, dr=dr, ol=ol, orr=orr, OM=OM, m=m,
+                sf=exl.GetScaleFactors(), sigma2=exl.GetScaleSigmaSquares())
+
+
+def test_grid_build_matches_oracle(pkg, scene):
+    a = pkg.FrameView(scene["kl"], scene["dl"], 752, 480, backend=scene["m"])
+    b = pkg.FrameView(scene["kl"], scene["dl"], 752, 480, backend=scene["OM"])
+    assert a.placed == b.placed == len(scene["kl"])
+    assert np.array_equal(a.grid_start, b.grid_start) and np.array_equal(a.grid_idx, b.grid_idx)
+    # keypoints outside the grid are dropped (posX == 64 after rounding) -- move some to the right edge
+    k2 = scene["kl"].copy(); k2["x"][:7] = 751.9; k2["y"][7:11] = 479.8
+    a = pkg.FrameView(k2, scene["dl"], 752, 480, backend=scene["m"]); b = pkg.FrameView(k2, scene["dl"], 752, 480, backend=scene["OM"])
+    assert a.placed == b.placed < len(k2)
+    assert np.array_equal(a.grid_start, b.grid_start) and np.array_equal(a.grid_idx[:a.placed], b.grid_idx[:b.placed])
+    # empty frame
+    e = pkg.FrameView(scene["kl"][:0], scene["dl"][:0], 752, 480, backend=scene["m"])
+    assert e.placed == 0 and e.grid_start[-1] == 0
+
+
+def test_window_candidates_order_and_distances(pkg, oracle, scene):
+    f = pkg.FrameView(scene["kr"], scene["dr"], 752, 480, backend=scene["m"])
+    rng = np.random.default_rng(1)
+    nq = 300
+    qx = rng.uniform(-20, 780, nq).astype(np.float32); qy = rng.uniform(-20, 500, nq).astype(np.float32)
+    qr = rng.uniform(2, 90, nq).astype(np.float32)
+    lo = rng.integers(-1, 6, nq).astype(np.int32); hi = (lo + rng.integers(-2, 3, nq)).astype(np.int32)
+    qd = scene["dl"][:nq]
+    cnt, idx, dist = scene["m"].window_candidates(f, qx, qy, qr, lo, hi, qd, cap=f.n)
+    for i in range(nq):
+        ref = scene["OM"].features_in_area(f, qx[i], qy[i], qr[i], lo[i], hi[i])
+        assert cnt[i] == len(ref) and np.array_equal(idx[i, :cnt[i]], ref)
+        for c in range(0, cnt[i], 7):
+            assert dist[i, c] == oracle.hamming(qd[i], scene["dr"][idx[i, c]])
+
+
+def _queries(scene, rng, jitter=3.0):
+    kl = scene["kl"]; n = len(kl)
+    u = (kl["x"] - 12.0 + rng.normal(0, jitter, n)).astype(np.float32)
+    v = (kl["y"] + rng.normal(0, jitter / 3, n)).astype(np.float32)
+    return n, u, v
+
+
+@pytest.mark.parametrize("th,fwd,bwd,stereo,ori", [(15, 0, 0, False, True), (7, 0, 0, True, True), (7, 1, 0, True, False),
+                                                    (7, 0, 1, True, True), (30, 0, 0, False, True)])
+def test_search_by_projection_frame(pkg, scene, th, fwd, bwd, stereo, ori):
+    rng = np.random.default_rng(th * 7 + fwd + 2 * bwd)
+    kr = scene["kr"]
+    ur = None
+    if stereo:
+        ur = np.where(rng.random(len(kr)) < 0.6, kr["x"] - rng.uniform(2, 40, len(kr)), -1).astype(np.float32)
+    views = [pkg.FrameView(kr, scene["dr"], 752, 480, uright=ur, backend=b) for b in (scene["m"], scene["OM"])]
+    n, u, v = _queries(scene, rng)
+    args = dict(cur_blocked=rng.random(len(kr)) < 0.05, scale_factors=scene["sf"], valid=rng.random(n) < 0.85, u=u, v=v,
+                invzc=rng.uniform(0.05, 1.0, n), octave=scene["kl"]["octave"], angle=scene["kl"]["angle"], qdesc=scene["dl"],
+                mp_obs=rng.random(n) < 0.9, th=th, forward=bool(fwd), backward=bool(bwd), mbf=47.9, check_ori=ori)
+    n_gpu, m_gpu = scene["m"].SearchByProjectionFrame(views[0], **args)
+    n_ref, m_ref = scene["OM"].SearchByProjectionFrame(views[1], **args)
+    assert n_gpu == n_ref and np.array_equal(m_gpu, m_ref)
+    assert n_ref > 50
+
+
+@pytest.mark.parametrize("th,nnratio,stereo", [(1.0, 0.8, False), (3.0, 0.8, True), (5.0, 0.9, False)])
+def test_search_by_projection_points(pkg, scene, th, nnratio, stereo):
+    rng = np.random.default_rng(int(th * 10))
+    kr = scene["kr"]
+    ur = np.where(rng.random(len(kr)) < 0.6, kr["x"] - rng.uniform(2, 40, len(kr)), -1).astype(np.float32) if stereo else None
+    views = [pkg.FrameView(kr, scene["dr"], 752, 480, uright=ur, backend=b) for b in (scene["m"], scene["OM"])]
+    n, u, v = _queries(scene, rng, jitter=2.0)
+    args = dict(blocked=rng.random(len(kr)) < 0.05, scale_factors=scene["sf"], in_view=rng.random(n) < 0.8, px=u, py=v,
+                pxr=(u - rng.uniform(2, 40, n)).astype(np.float32), view_cos=rng.uniform(0.99, 1.0, n),
+                level=scene["kl"]["octave"], qdesc=scene["dl"], mp_obs=rng.random(n) < 0.9, th=th, nnratio=nnratio)
+    n_gpu, m_gpu = scene["m"].SearchByProjectionPoints(views[0], **args)
+    n_ref, m_ref = scene["OM"].SearchByProjectionPoints(views[1], **args)
+    assert n_gpu == n_ref and np.array_equal(m_gpu, m_ref)
+    assert n_ref > 20
+
+
+@pytest.mark.parametrize("ori", [True, False])
+def test_search_for_initialization(pkg, oracle, synth, scene, ori):
+    # Tracking.cc:1113: the initialisation extractor uses 5*nFeatures; window 100 (Tracking.cc:2684-2688)
+    ex = pkg.ORBextractor(5000, max_size=(752, 480))
+    _, k1, d1 = ex(scene["l"], (0, 1000)); _, k2, d2 = ex(scene["r"], (0, 1000))
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    out = []
+    for b in (scene["m"], scene["OM"]):
+        f1 = pkg.FrameView(k1, d1, 752, 480, backend=b); f2 = pkg.FrameView(k2, d2, 752, 480, backend=b)
+        out.append(b.SearchForInitialization(f1, f2, prev, 100, 0.9, ori))
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert out[0][0] > 30
+
+
+def _fv(pkg, desc, bits):
+    return pkg.feature_vector_csr(desc[:, 0].astype(np.int64) & ((1 << bits) - 1))
+
+
+@pytest.mark.parametrize("bits,only_stereo,coarse,ori", [(6, False, False, False), (4, False, True, True), (8, True, False, False)])
+def test_search_for_triangulation(pkg, scene, bits, only_stereo, coarse, ori):
+    rng = np.random.default_rng(bits)
+    kl, kr, dl, dr = scene["kl"], scene["kr"], scene["dl"], scene["dr"]
+    # fundamental matrix of a sideways motion + a little rotation (rows of x1' F12 = epipolar lines in image 2)
+    F12 = np.array([[1e-7, -3e-6, 1.1e-3], [2.5e-6, 2e-7, -0.0231], [-1.3e-3, 0.0229, 0.35]], np.float32)
+    args = dict(k1=kl, d1=dl, has_mp1=rng.random(len(kl)) < 0.3, ur1=np.where(rng.random(len(kl)) < 0.5, 5.0, -1.0),
+                fv1=_fv(pkg, dl, bits), k2=kr, d2=dr, has_mp2=rng.random(len(kr)) < 0.3,
+                ur2=np.where(rng.random(len(kr)) < 0.5, 5.0, -1.0), fv2=_fv(pkg, dr, bits), F12=F12, ep=(900.0, 240.0),
+                sf2=scene["sf"], sigma2_2=scene["sigma2"], only_stereo=only_stereo, coarse=coarse, check_ori=ori)
+    n_gpu, m_gpu = scene["m"].SearchForTriangulation(**args)
+    n_ref, m_ref = scene["OM"].SearchForTriangulation(**args)
+    assert n_gpu == n_ref and np.array_equal(m_gpu, m_ref)
+    if coarse:
+        assert n_ref > 10
+
+
+@pytest.mark.parametrize("bits,nnratio,ori", [(6, 0.7, True), (4, 0.75, False), (9, 0.9, True)])
+def test_search_by_bow(pkg, scene, bits, nnratio, ori):
+    rng = np.random.default_rng(bits + 100)
+    kl, kr, dl, dr = scene["kl"], scene["kr"], scene["dl"], scene["dr"]
+    args = dict(kkf=kl, dkf=dl, kf_good=rng.random(len(kl)) < 0.7, fvk=_fv(pkg, dl, bits), kf_=kr, df=dr, fvf=_fv(pkg, dr, bits),
+                nnratio=nnratio, check_ori=ori)
+    n_gpu, m_gpu = scene["m"].SearchByBoW(**args)
+    n_ref, m_ref = scene["OM"].SearchByBoW(**args)
+    assert n_gpu == n_ref and np.array_equal(m_gpu, m_ref)
+
+
+def test_compute_stereo_matches(pkg, scene):
+    # EuRoC stereo: bf = 47.906, fx = 435.2 -> mb = bf/fx (Examples/Stereo/EuRoC.yaml:9,28)
+    mbf = 47.90639384423901; mb = mbf / 435.2046959714599
+    n_gpu, ur_g, dp_g = scene["m"].ComputeStereoMatches(scene["exl"], scene["exr"], scene["kl"], scene["dl"], scene["kr"], scene["dr"], mb, mbf)
+    n_ref, ur_r, dp_r = scene["OM"].ComputeStereoMatches(scene["ol"], scene["orr"], scene["kl"], scene["dl"], scene["kr"], scene["dr"], mb, mbf)
+    assert n_gpu == n_ref and n_ref > 300
+    assert ur_g.tobytes() == ur_r.tobytes() and dp_g.tobytes() == dp_r.tobytes()
+    ok = ur_g >= 0
+    d = scene["kl"]["x"][ok] - ur_g[ok]
+    assert np.all(d > 0) and np.all(d < mbf / mb)
+
+
+def test_searches_handle_empty_inputs(pkg, scene):
+    m, kl, dl = scene["m"], scene["kl"], scene["dl"]
+    empty = pkg.FrameView(kl[:0], dl[:0], 752, 480, backend=m)
+    full = pkg.FrameView(kl, dl, 752, 480, backend=m)
+    z = np.zeros(0)
+    n, match = m.SearchByProjectionFrame(full, np.zeros(len(kl)), scene["sf"], z, z, z, z, z, z, dl[:0], z, 15)
+    assert n == 0 and np.all(match == -1)
+    n, m12, _ = m.SearchForInitialization(empty, full, np.zeros((0, 2), np.float32), 100, 0.9)
+    assert n == 0 and len(m12) == 0
