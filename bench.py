@@ -108,18 +108,15 @@ def main():
     dt = time.perf_counter() - t0
 
     counts = ex.result_device()
-    n_host = dev_counts = None
-    cnt = pkg.DeviceBuffer(4 * B)                          # keypoint counts of the last batch
-    L.orbx_memcpy_d2h  # (bound)
-    n_host = np.zeros(B, np.int32)
+    n_host = np.zeros(B, np.int32)                         # keypoint counts of the last batch
     L.orbx_memcpy_d2h(n_host.ctypes.data_as(C.c_void_p), counts["counts"], 4 * B)
+    dmod = importlib.import_module("orb-slam3_amd.dist")
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    total_kp = torch.tensor([int(n_host.sum())], dtype=torch.int64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        gathered = [torch.zeros_like(total_kp) for _ in range(world)]
-        dist.all_gather(gathered, total_kp)                # RCCL: the path's only exchange (keypoint counts)
-        total_kp = torch.stack(gathered).sum()
+    # RCCL: the path's only exchange -- per-frame keypoint counts of every rank
+    gathered = dmod.gather_counts(n_host, device="cuda")
+    total_kp = torch.stack([g.sum() for g in gathered]).sum()
     dt = float(tmax.item())
 
     if rank == 0:

@@ -1,0 +1,26 @@
+// Compiles the C++ facade against the minimal cv-compat layer and (on a GPU box) runs one extraction through it.
+#include <cstdio>
+#include <vector>
+#include "../orb-slam3_amd/facade/ORBextractor.h"
+#include "../orb-slam3_amd/facade/ORBmatcher.h"
+
+int main(int argc, char** argv) {
+    const int w = 752, h = 480;
+    std::vector<uint8_t> buf((size_t)w * h);
+    unsigned s = 12345;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) { s = s * 1664525u + 1013904223u; buf[(size_t)y * w + x] = (uint8_t)(((x / 16 + y / 16) & 1) * 120 + 60 + (s >> 28)); }
+    cv::Mat img(h, w, cv::CV_8U, buf.data());
+    if (orbx_device_count() < 1) { std::printf("facade compiled; no GPU here\n"); return argc > 1 ? 1 : 0; }
+    ORB_SLAM3::ORBextractor ex(1000, 1.2f, 8, 20, 7);
+    std::vector<cv::KeyPoint> kps; cv::Mat desc; std::vector<int> lap = {0, 1000};
+    const int mono = ex(img, cv::Mat(), kps, desc, lap);
+    std::printf("facade: %zu keypoints, mono=%d, desc %dx%d, levels=%d sf1=%.3f\n", kps.size(), mono, desc.rows, desc.cols,
+                ex.GetLevels(), ex.GetScaleFactors()[1]);
+    if (kps.empty() || desc.rows != (int)kps.size()) return 2;
+    ex.FetchImagePyramid();
+    if (ex.mvImagePyramid[1].cols != 627) return 3;
+    ORB_SLAM3::ORBmatcher m(0.7f);
+    if (ORB_SLAM3::ORBmatcher::DescriptorDistance(desc.row(0), desc.row(0)) != 0) return 4;
+    return 0;
+}

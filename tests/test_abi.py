@@ -50,3 +50,15 @@ def test_scalar_helpers_on_cpu(pkg, oracle):
     assert pkg.ORBmatcher.DescriptorDistance(a, b) == oracle.hamming(a, b) == int(np.unpackbits(a ^ b).sum())
     c = rng.integers(0, 9, 30).astype(np.int32)
     assert np.array_equal(pkg.ORBmatcher.ComputeThreeMaxima(c), oracle.three_maxima(c))
+
+
+def test_cpp_facade_compiles_against_the_c_abi(pkg, tmp_path):
+    """The drop-in C++ classes (facade/ORBextractor.h, ORBmatcher.h) build with plain g++ and link the library."""
+    import subprocess
+    pkg.build()
+    exe = str(tmp_path / "facade_smoke")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "facade_smoke.cpp"),
+                           "-L", os.path.join(ROOT, "orb-slam3_amd"), "-lorbslam3_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "orb-slam3_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr

@@ -94,3 +94,16 @@ def test_getters_match_oracle_tables(pkg, oracle):
     assert np.array_equal(ex.GetScaleFactors(), t["sf"]) and np.array_equal(ex.GetInverseScaleFactors(), t["inv_sf"])
     assert np.array_equal(ex.GetScaleSigmaSquares(), t["sig2"]) and np.array_equal(ex.GetInverseScaleSigmaSquares(), t["inv_sig2"])
     assert np.array_equal(ex.features_per_level(), t["nfeat"]) and ex.GetLevels() == 8
+
+
+def test_cpp_facade_runs(pkg, tmp_path):
+    """ORB_SLAM3::ORBextractor / ORBmatcher facade classes end to end on the GPU (argv[1] makes 'no GPU' an error)."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "facade_smoke")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(root, "tests", "facade_smoke.cpp"),
+                           "-L", os.path.join(root, "orb-slam3_amd"), "-lorbslam3_amd",
+                           "-Wl,-rpath," + os.path.join(root, "orb-slam3_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, "need-gpu"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "keypoints" in out.stdout
