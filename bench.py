@@ -124,6 +124,14 @@ def main():
         alg, fused = ex.algorithmic_bytes()
         pf_ms = float(np.mean(t_pyr) + np.mean(t_fast))
         achieved = alg * B / (pf_ms * 1e-3) / 1e9
+        traffic = None                                      # HBM bytes/launch-group from the committed rocprofv3 --pmc passes
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            c = tj["config"]
+            if (c["width"], c["height"], c["nfeatures"]) == (W, H, args.nfeatures):
+                traffic = tj["pyramid_fast_bytes_per_frame"] * B
+        except Exception:
+            traffic = None
         stage = {k: float(np.mean([t[k] for t in t_all])) for k in t_all[0]}
         stage["knn2"] = mt.timing_ms()
         out = {
@@ -137,7 +145,7 @@ def main():
                        "frames_per_step_per_gpu": B, "keypoints_last_batch": int(total_kp.item())},
             "roofline": {"bound": "hbm", "kernel": "pyramid+FAST pass (k_resize x7 + k_fast)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_frame": alg, "fused_lower_bound_per_frame": fused,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg * B, "algorithmic_bytes_per_frame": alg, "fused_lower_bound_per_frame": fused,
                          "launch_ms": pf_ms},
             "stage_ms_per_step": stage,
         }
