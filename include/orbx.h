@@ -83,9 +83,11 @@ int orbx_level_candidates(orbx_t*, int frame, int level, int32_t* xyr, int cap);
 /* keypoints chosen by the quadtree for (frame, level) in list order: (x,y,response) in level coordinates */
 int orbx_level_selected(orbx_t*, int frame, int level, int32_t* xyr, int cap);
 
-/* timing: HIP events around the most recent async batch, per kernel group [ms]:
- * 0 pyramid(resize), 1 fast, 2 quadtree, 3 slots, 4 blur, 5 orient+descriptor, 6 total */
-int orbx_last_timings(orbx_t*, float* ms7);
+/* timing: HIP events of the most recent async batch, recorded on the stream each kernel group is launched on [ms]:
+ * 0 pyramid (resize chain, stream 2), 1 FAST (level 0 + levels 1.., stream 1), 2 quadtree, 3 slots, 4 blur (stream 2),
+ * 5 orient+descriptor, 6 total, 7 wall span from the first resize/FAST launch to the end of the last FAST launch
+ * (the two streams overlap, so 0+1 double-counts; 7 is the figure the roofline uses).  ms8 holds 8 floats. */
+int orbx_last_timings(orbx_t*, float* ms8);
 /* algorithmic bytes of the pyramid+FAST pass for one frame of the current geometry */
 int64_t orbx_algorithmic_bytes(const orbx_t*, int64_t* fused_lower_bound);
 void* orbx_stream(const orbx_t*);     /* hipStream_t the kernels are launched on */

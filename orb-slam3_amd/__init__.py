@@ -265,9 +265,9 @@ class ORBextractor:
         return out[:n]
 
     def timings(self):
-        t = np.zeros(7, np.float32)
+        t = np.zeros(8, np.float32)
         _chk(self.L.orbx_last_timings(self.h, _p(t)), "timings")
-        return dict(zip(["pyramid", "fast", "quadtree", "slots", "blur", "orient_desc", "total"], t.tolist()))
+        return dict(zip(["pyramid", "fast", "quadtree", "slots", "blur", "orient_desc", "total", "pyramid_fast_span"], t.tolist()))
 
     def algorithmic_bytes(self):
         f = C.c_int64()

@@ -56,10 +56,12 @@ struct orbx {
     int64_t algBytes = 0, fusedBytes = 0;
     size_t qtLds = 0, qt2Lds = 0;
     int qt2Cap = 0, qt2Sort = 0;
-    bool qtV1 = false;
+    bool qtV1 = false, odV1 = false;
     // device
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev[12] = {};
+    int nStrips0 = 0;
     u8 *dPyr = nullptr, *dBlur = nullptr, *dL0 = nullptr;
     const u8** dL0Ptr = nullptr;
     CellInfo* dCells = nullptr; BlurTask* dTiles = nullptr; RzTab *dXt = nullptr, *dYt = nullptr;
@@ -305,6 +307,8 @@ static int build_geometry(orbx* o, int w, int h) {
     HIPCHK(hipMemcpy(o->dStrips, o->strips.data(), o->strips.size() * sizeof(StripInfo), hipMemcpyHostToDevice));
     if (!o->xt.empty()) HIPCHK(hipMemcpy(o->dXt, o->xt.data(), o->xt.size() * sizeof(RzTab), hipMemcpyHostToDevice));
     if (!o->yt.empty()) HIPCHK(hipMemcpy(o->dYt, o->yt.data(), o->yt.size() * sizeof(RzTab), hipMemcpyHostToDevice));
+    o->nStrips0 = 0;
+    for (const StripInfo& stp : o->strips) if (stp.level == 0) ++o->nStrips0;
     o->f3Tile = align_up(o->f3Tile, 16);
     o->f3Lds = (size_t)2 * o->f3Tile + (size_t)(F3_NT / 64) * o->f3Qcap * 2;
     if (o->f3Lds > 160 * 1024 - 256) { set_err("FAST strip needs %zu B of LDS", o->f3Lds); return ORBX_E_UNSUPPORTED; }
@@ -341,7 +345,8 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     o->nfeatures = nfeatures; o->nlevels = nlevels; o->iniTh = ini_th; o->minTh = min_th; o->device = device_id;
     o->maxW = max_w; o->maxH = max_h; o->maxBatch = max_batch;
     o->fastV1 = getenv("ORBX_FAST_V1") != nullptr;
-    o->qtV1 = getenv("ORBX_QT_V1") != nullptr;            // A/B switch: simple per-cell reference kernel
+    o->qtV1 = getenv("ORBX_QT_V1") != nullptr;
+    o->odV1 = getenv("ORBX_OD_V1") != nullptr;            // A/B switch: simple per-cell reference kernel
     o->scaleFactor = scale_factor;                              // double member initialised from float (ORBextractor.h:96)
     const int L = nlevels;
     o->sf.resize(L); o->sig2.resize(L); o->invsf.resize(L); o->invsig2.resize(L); o->nfeat.resize(L);
@@ -361,7 +366,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     }
     int rc = ORBX_OK;
     do {
-        if (hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipStreamCreate failed"); break; }
+        if (hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&o->stream2, hipStreamNonBlocking) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipStreamCreate failed"); break; }
         for (auto& e : o->ev) if (hipEventCreate(&e) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); break; }
         if (rc) break;
         const size_t B = max_batch;
@@ -382,11 +387,13 @@ void orbx_destroy(orbx_t* o) {
     if (!o) return;
     (void)hipSetDevice(o->device);
     if (o->stream) (void)hipStreamSynchronize(o->stream);
+    if (o->stream2) (void)hipStreamSynchronize(o->stream2);
     void* ptrs[] = {o->dPyr, o->dBlur, o->dL0, (void*)o->dL0Ptr, o->dCells, o->dTiles, o->dStrips, o->dX4, o->dRzTasks, o->dXt, o->dYt, o->dCandCnt, o->dCandEnt,
                     o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->dKps, o->dDesc, o->dWork, o->dN, o->dMono, o->dLap, o->dErr, o->dPattern, o->dStamps};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : o->ev) if (e) (void)hipEventDestroy(e);
     if (o->stream) (void)hipStreamDestroy(o->stream);
+    if (o->stream2) (void)hipStreamDestroy(o->stream2);
     delete o;
 }
 
@@ -430,24 +437,45 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     HIPCHK(hipMemcpyAsync(o->dLap, o->hLap.data(), sizeof(int) * 2 * nimg, hipMemcpyHostToDevice, st));
 
     o->lastL0Pitch = l0pitch;
+    // Two HIP streams (events order them): the resize chain + blur are latency-bound and leave the VALUs idle, FAST is
+    // VALU-bound -- so level-0 FAST (needs no resize) runs beside the resize chain and levels 1..7 beside the blur.
+    //   s0: FAST(L0) --wait pyramid--> FAST(L1..) -> quadtree -> slots --wait blur--> orientation+descriptors
+    //   s1: resize L1..L7 -> [pyramid ready] -> blur -> [blur ready]
+    hipStream_t s1 = o->stream2;
     HIPCHK(hipEventRecord(o->ev[0], st));
+    HIPCHK(hipStreamWaitEvent(s1, o->ev[0], 0));                 // inputs uploaded; previous batch's readers of the pyramid are done
+    HIPCHK(hipEventRecord(o->ev[7], s1));
     for (int l = 1; l < g.nlevels; ++l) {
         if (o->rzStream[l]) {
             const int nt = (int)o->rzTasks[l].size();
-            hipLaunchKernelGGL(k_resize2, dim3((nt + 3) / 4, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr,
+            hipLaunchKernelGGL(k_resize2, dim3((nt + 3) / 4, nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr,
                                o->dRzTasks + o->rzTaskOff[l], nt, o->dX4, o->dYt);
-        } else {                                                 // general fallback (large scale factors, tight level-0 strides)
+        } else {                                                 // general fallback (large scale factors)
             dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, nimg), block(64, 4);
-            hipLaunchKernelGGL(k_resize, grid, block, 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, l, o->dXt, o->dYt);
+            hipLaunchKernelGGL(k_resize, grid, block, 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, l, o->dXt, o->dYt);
         }
     }
-    HIPCHK(hipEventRecord(o->ev[1], st));
-    if (o->fastV1)
+    HIPCHK(hipEventRecord(o->ev[8], s1));                        // pyramid ready
+    hipLaunchKernelGGL(k_blur2, dim3((unsigned)(o->tiles.size() + 3) / 4, nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
+                       o->dTiles, (int)o->tiles.size(), o->blurSel);
+    HIPCHK(hipEventRecord(o->ev[9], s1));                        // blur ready
+    if (o->fastV1) {
+        HIPCHK(hipStreamWaitEvent(st, o->ev[8], 0));
+        HIPCHK(hipEventRecord(o->ev[1], st));
         hipLaunchKernelGGL(k_fast, dim3(g.totalCells, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dCells,
                            o->dCandCnt, o->dCandEnt, o->dErr);
-    else
-        hipLaunchKernelGGL(k_fast3, dim3((unsigned)o->strips.size(), nimg), dim3(F3_NT), o->f3Lds, st, g, o->dL0Ptr, l0pitch, o->dPyr,
+        HIPCHK(hipEventRecord(o->ev[10], st));
+    } else {
+        const unsigned n0 = (unsigned)o->nStrips0, nAll = (unsigned)o->strips.size();
+        hipLaunchKernelGGL(k_fast3, dim3(n0, nimg), dim3(F3_NT), o->f3Lds, st, g, o->dL0Ptr, l0pitch, o->dPyr,
                            o->dCells, o->dStrips, o->dCandCnt, o->dCandEnt, o->dErr, o->f3Tile, o->f3Qcap);
+        HIPCHK(hipEventRecord(o->ev[10], st));                   // level-0 FAST done
+        HIPCHK(hipStreamWaitEvent(st, o->ev[8], 0));
+        HIPCHK(hipEventRecord(o->ev[1], st));
+        if (nAll > n0)
+            hipLaunchKernelGGL(k_fast3, dim3(nAll - n0, nimg), dim3(F3_NT), o->f3Lds, st, g, o->dL0Ptr, l0pitch, o->dPyr,
+                               o->dCells, o->dStrips + n0, o->dCandCnt, o->dCandEnt, o->dErr, o->f3Tile, o->f3Qcap);
+    }
     HIPCHK(hipEventRecord(o->ev[2], st));
     if (o->qtV1)
         hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, nimg), dim3(256), o->qtLds, st, g, o->dCells, o->dCandCnt, o->dCandEnt,
@@ -460,11 +488,14 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     HIPCHK(hipEventRecord(o->ev[3], st));
     hipLaunchKernelGGL(k_slots, dim3(nimg), dim3(256), 0, st, g, o->dSel, o->dSelCnt, o->dLap, o->dKps, o->dWork, o->dN, o->dMono);
     HIPCHK(hipEventRecord(o->ev[4], st));
-    hipLaunchKernelGGL(k_blur2, dim3((unsigned)(o->tiles.size() + 3) / 4, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
-                       o->dTiles, (int)o->tiles.size(), o->blurSel);
+    HIPCHK(hipStreamWaitEvent(st, o->ev[9], 0));
     HIPCHK(hipEventRecord(o->ev[5], st));
-    hipLaunchKernelGGL(k_orient_desc, dim3((g.kpCap + 3) / 4, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
-                       o->dWork, o->dN, o->dKps, o->dDesc, o->dPattern, o->umax);
+    if (o->odV1)
+        hipLaunchKernelGGL(k_orient_desc, dim3((g.kpCap + 3) / 4, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
+                           o->dWork, o->dN, o->dKps, o->dDesc, o->dPattern, o->umax);
+    else
+        hipLaunchKernelGGL(k_orient_desc2, dim3((g.kpCap + 15) / 16, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
+                           o->dWork, o->dN, o->dKps, o->dDesc, o->dPattern, o->umax);
     HIPCHK(hipEventRecord(o->ev[6], st));
     HIPCHK(hipGetLastError());
     o->lastBatch = nimg;
@@ -476,6 +507,7 @@ int orbx_sync(orbx_t* o) {
     if (!o) return ORBX_E_INVALID;
     HIPCHK(hipSetDevice(o->device));
     HIPCHK(hipStreamSynchronize(o->stream));
+    HIPCHK(hipStreamSynchronize(o->stream2));
     int e = 0;
     HIPCHK(hipMemcpy(&e, o->dErr, sizeof(int), hipMemcpyDeviceToHost));
     if (e) { set_err("device-side overflow flag %d", e); (void)hipMemset(o->dErr, 0, sizeof(int)); return ORBX_E_INTERNAL; }
@@ -605,12 +637,22 @@ int orbx_level_selected(orbx_t* o, int frame, int level, int32_t* xyr, int cap) 
     return (int)n;
 }
 
-int orbx_last_timings(orbx_t* o, float* ms7) {
+int orbx_last_timings(orbx_t* o, float* ms7) {   // 8 floats, see include/orbx.h
     if (!o || !o->timed) return ORBX_E_INVALID;
     HIPCHK(hipSetDevice(o->device));
     HIPCHK(hipStreamSynchronize(o->stream));
-    for (int i = 0; i < 6; ++i) HIPCHK(hipEventElapsedTime(&ms7[i], o->ev[i], o->ev[i + 1]));
+    HIPCHK(hipStreamSynchronize(o->stream2));
+    float f0 = 0, f1 = 0;
+    HIPCHK(hipEventElapsedTime(&ms7[0], o->ev[7], o->ev[8]));      // resize chain (stream 2)
+    HIPCHK(hipEventElapsedTime(&f0, o->ev[0], o->ev[10]));         // FAST level 0 (fastV1: whole FAST is ev1->ev10)
+    HIPCHK(hipEventElapsedTime(&f1, o->ev[1], o->fastV1 ? o->ev[10] : o->ev[2]));
+    ms7[1] = o->fastV1 ? f1 : f0 + f1;
+    HIPCHK(hipEventElapsedTime(&ms7[2], o->ev[2], o->ev[3]));
+    HIPCHK(hipEventElapsedTime(&ms7[3], o->ev[3], o->ev[4]));
+    HIPCHK(hipEventElapsedTime(&ms7[4], o->ev[8], o->ev[9]));      // blur (stream 2)
+    HIPCHK(hipEventElapsedTime(&ms7[5], o->ev[5], o->ev[6]));
     HIPCHK(hipEventElapsedTime(&ms7[6], o->ev[0], o->ev[6]));
+    HIPCHK(hipEventElapsedTime(&ms7[7], o->ev[0], o->ev[2]));      // wall span of the pyramid+FAST pass (both streams)
     return ORBX_OK;
 }
 
