@@ -101,6 +101,13 @@ int orbm_search_by_projection_points(orbm_t*, const orbm_frame_t* f, const uint8
                                      const float* view_cos, const int32_t* level, const uint8_t* qdesc, const uint8_t* mp_obs,
                                      float th, float nnratio, int32_t* match);
 
+/* M5  ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:2723-2852), relocalisation.
+ * valid[i] folds the caller-side gates (MapPoint present / not bad / not already found / projection in bounds /
+ * distance invariance); level[i] = PredictScale; blocked[i2] = CurrentFrame.mvpMapPoints[i2] != NULL. */
+int orbm_search_by_projection_kf(orbm_t*, const orbm_frame_t* cur, const uint8_t* blocked, const float* scale_factors,
+                                 int nq, const uint8_t* valid, const float* u, const float* v, const int32_t* level,
+                                 const float* angle, const uint8_t* qdesc, float th, int orb_dist, int check_ori, int32_t* match);
+
 /* M9  ORBmatcher::SearchForInitialization (ORBmatcher.cc:799-943); prev_matched_xy is updated in place */
 int orbm_search_for_initialization(orbm_t*, const orbm_frame_t* f1, const orbm_frame_t* f2, float* prev_matched_xy,
                                    int window, float nnratio, int check_ori, int32_t* matches12);
@@ -121,6 +128,22 @@ int orbm_search_by_bow(orbm_t*, int nkf, const orbm_kp_t* kps_kf, const uint8_t*
                        int nf, const orbm_kp_t* kps_f, const uint8_t* desc_f,
                        int nnf, const int32_t* nodes_f, const int32_t* start_f, const int32_t* idx_f,
                        float nnratio, int check_ori, int32_t* f_match);
+
+/* M8  ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (ORBmatcher.cc:955-1105); matches12[idx1] = idx2 or -1 */
+int orbm_search_by_bow_kf(orbm_t*, int n1, const orbm_kp_t* kps1, const uint8_t* desc1, const uint8_t* good1,
+                          int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
+                          int n2, const orbm_kp_t* kps2, const uint8_t* desc2, const uint8_t* good2,
+                          int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2,
+                          float nnratio, int check_ori, int32_t* matches12);
+
+/* M11 ORBmatcher::SearchForTriangulation, cv::Mat F12 overload (ORBmatcher.cc:1107-1386): as M10 but vbMatched2 is kept
+ * (set :1319, cleared by the orientation cull :1366) and the histogram factor is 30/360 (:1166). */
+int orbm_search_for_triangulation_legacy(orbm_t*, int n1, const orbm_kp_t* kps1, const uint8_t* desc1, const uint8_t* has_mp1, const float* uright1,
+                                  int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
+                                  int n2, const orbm_kp_t* kps2, const uint8_t* desc2, const uint8_t* has_mp2, const float* uright2,
+                                  int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2,
+                                  const float* F12, float epx, float epy, const float* scale_factors2, const float* level_sigma2_2,
+                                  int only_stereo, int coarse, int check_ori, int32_t* matches12);
 
 /* M15 Frame::ComputeStereoMatches (Frame.cc:1027-1276).  left/right are orbx_t* extractor handles (include/orbx.h)
  * on the same device whose LAST call produced the two keypoint sets: their device-resident pyramids supply the

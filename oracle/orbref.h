@@ -118,6 +118,26 @@ int orbref_search_by_bow(int nkf, const orbref_kp_t* kps_kf, const uint8_t* desc
                          int nf, const orbref_kp_t* kps_f, const uint8_t* desc_f,
                          int nnf, const int32_t* nodes_f, const int32_t* start_f, const int32_t* idx_f,
                          float nnratio, int check_ori, int32_t* f_match);
+/* ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:2723-2852).
+ * valid[i] folds: MapPoint present, not bad, not already found, projection in bounds, distance gates; level[i] is
+ * PredictScale's result.  blocked[i2] = CurrentFrame.mvpMapPoints[i2] != NULL. */
+int orbref_search_by_projection_kf(const orbref_frame_t* cur, const uint8_t* blocked, const float* scale_factors,
+                                   int nq, const uint8_t* valid, const float* u, const float* v, const int32_t* level,
+                                   const float* angle, const uint8_t* qdesc, float th, int orb_dist, int check_ori, int32_t* match);
+/* ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (ORBmatcher.cc:955-1105); matches12[idx1] = idx2 or -1 */
+int orbref_search_by_bow_kf(int n1, const orbref_kp_t* kps1, const uint8_t* desc1, const uint8_t* good1,
+                            int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
+                            int n2, const orbref_kp_t* kps2, const uint8_t* desc2, const uint8_t* good2,
+                            int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2,
+                            float nnratio, int check_ori, int32_t* matches12);
+/* ORBmatcher::SearchForTriangulation (cv::Mat F12 overload, ORBmatcher.cc:1107-1386): as the _ variant but
+ * vbMatched2 is maintained (set :1319, cleared on the orientation cull :1366) and factor = 30/360. */
+int orbref_search_for_triangulation_legacy(int n1, const orbref_kp_t* kps1, const uint8_t* desc1, const uint8_t* has_mp1, const float* uright1,
+                                    int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
+                                    int n2, const orbref_kp_t* kps2, const uint8_t* desc2, const uint8_t* has_mp2, const float* uright2,
+                                    int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2,
+                                    const float* F12, float epx, float epy, const float* scale_factors2, const float* level_sigma2_2,
+                                    int only_stereo, int coarse, int check_ori, int32_t* matches12);
 /* Frame::ComputeStereoMatches (Frame.cc:1027-1276).  Pyramids are those of the two extractors' last call. */
 int orbref_stereo_matches(const orbref_t* left, const orbref_t* right,
                           int nl, const orbref_kp_t* kl, const uint8_t* dl, int nr, const orbref_kp_t* kr, const uint8_t* dr,

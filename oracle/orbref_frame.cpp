@@ -346,6 +346,154 @@ int orbref_search_by_bow(int nkf, const orbref_kp_t* kps_kf, const uint8_t* desc
     return nmatches;
 }
 
+
+int orbref_search_by_projection_kf(const orbref_frame_t* cur, const uint8_t* blocked_in, const float* sf,
+                                   int nq, const uint8_t* valid, const float* u, const float* v, const int32_t* level,
+                                   const float* angle, const uint8_t* qdesc, float th, int ORBdist, int check_ori, int32_t* match) {
+    int nmatches = 0;
+    RotHist rh;
+    const float factor = HISTO_LENGTH / 360.0f;                               // ORBmatcher.cc:2736
+    std::vector<uint8_t> taken(blocked_in, blocked_in + cur->n);
+    for (int i = 0; i < cur->n; ++i) match[i] = -1;
+    std::vector<int> vIndices2;
+    for (int i = 0; i < nq; ++i) {
+        if (!valid[i]) continue;
+        const int nPredictedLevel = level[i];
+        const float radius = th * sf[nPredictedLevel];
+        features_in_area(cur, u[i], v[i], radius, nPredictedLevel - 1, nPredictedLevel + 1, vIndices2);
+        if (vIndices2.empty()) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            if (taken[i2]) continue;                                          // :2793 (any MapPoint, observations not consulted)
+            const int dist = orbref_hamming(qdesc + 32 * (size_t)i, cur->desc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= ORBdist) {
+            match[bestIdx2] = i; taken[bestIdx2] = 1;
+            nmatches++;
+            if (check_ori) rh.add(angle[i], cur->kps[bestIdx2].angle, factor, bestIdx2);
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int b = 0; b < HISTO_LENGTH; ++b)
+            if (b != ind[0] && b != ind[1] && b != ind[2])
+                for (int idx : rh.bins[b]) { match[idx] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
+int orbref_search_by_bow_kf(int n1, const orbref_kp_t* kps1, const uint8_t* desc1, const uint8_t* good1,
+                            int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1v,
+                            int n2, const orbref_kp_t* kps2, const uint8_t* desc2, const uint8_t* good2,
+                            int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2v,
+                            float nnratio, int check_ori, int32_t* vpMatches12) {
+    for (int i = 0; i < n1; ++i) vpMatches12[i] = -1;
+    std::vector<bool> vbMatched2(n2, false);
+    RotHist rh;
+    const float factor = HISTO_LENGTH / 360.0f;                               // :978
+    int nmatches = 0, a = 0, b = 0;
+    while (a < nn1 && b < nn2) {
+        if (nodes1[a] == nodes2[b]) {
+            for (int i1 = start1[a]; i1 < start1[a + 1]; ++i1) {
+                const int idx1 = idx1v[i1];
+                if (!good1[idx1]) continue;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int i2 = start2[b]; i2 < start2[b + 1]; ++i2) {
+                    const int idx2 = idx2v[i2];
+                    if (vbMatched2[idx2] || !good2[idx2]) continue;
+                    const int dist = orbref_hamming(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < TH_LOW) {                                     // strict (:1047)
+                    if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                        vpMatches12[idx1] = bestIdx2;
+                        vbMatched2[bestIdx2] = true;
+                        if (check_ori) rh.add(kps1[idx1].angle, kps2[bestIdx2].angle, factor, idx1);
+                        nmatches++;
+                    }
+                }
+            }
+            ++a; ++b;
+        } else if (nodes1[a] < nodes2[b]) {
+            a = (int)(std::lower_bound(nodes1, nodes1 + nn1, nodes2[b]) - nodes1);
+        } else {
+            b = (int)(std::lower_bound(nodes2, nodes2 + nn2, nodes1[a]) - nodes2);
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int bb = 0; bb < HISTO_LENGTH; ++bb) {
+            if (bb == ind[0] || bb == ind[1] || bb == ind[2]) continue;
+            for (int i : rh.bins[bb]) { vpMatches12[i] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+int orbref_search_for_triangulation_legacy(int n1, const orbref_kp_t* kps1, const uint8_t* desc1, const uint8_t* has_mp1, const float* uright1,
+                                    int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1v,
+                                    int n2, const orbref_kp_t* kps2, const uint8_t* desc2, const uint8_t* has_mp2, const float* uright2,
+                                    int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2v,
+                                    const float* F12, float epx, float epy, const float* sf2, const float* sigma2_2,
+                                    int bOnlyStereo, int bCoarse, int check_ori, int32_t* vMatches12) {
+    int nmatches = 0;
+    std::vector<bool> vbMatched2(n2, false);
+    for (int i = 0; i < n1; ++i) vMatches12[i] = -1;
+    RotHist rh;
+    const float factor = HISTO_LENGTH / 360.0f;                               // :1166
+    int a = 0, b = 0;
+    while (a < nn1 && b < nn2) {
+        if (nodes1[a] == nodes2[b]) {
+            for (int i1 = start1[a]; i1 < start1[a + 1]; ++i1) {
+                const int idx1 = idx1v[i1];
+                if (has_mp1[idx1]) continue;
+                const bool bStereo1 = uright1 && uright1[idx1] >= 0;
+                if (bOnlyStereo && !bStereo1) continue;
+                const orbref_kp_t& kp1 = kps1[idx1];
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int i2 = start2[b]; i2 < start2[b + 1]; ++i2) {
+                    const int idx2 = idx2v[i2];
+                    if (vbMatched2[idx2] || has_mp2[idx2]) continue;
+                    const bool bStereo2 = uright2 && uright2[idx2] >= 0;
+                    if (bOnlyStereo && !bStereo2) continue;
+                    const int dist = orbref_hamming(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const orbref_kp_t& kp2 = kps2[idx2];
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = epx - kp2.x, distey = epy - kp2.y;
+                        if (distex * distex + distey * distey < 100 * sf2[kp2.octave]) continue;
+                    }
+                    if (epipolar_constrain(F12, kp1, kp2, sigma2_2[kp2.octave]) || bCoarse) { bestIdx2 = idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    vMatches12[idx1] = bestIdx2;
+                    vbMatched2[bestIdx2] = true;                              // :1319
+                    nmatches++;
+                    if (check_ori) rh.add(kp1.angle, kps2[bestIdx2].angle, factor, idx1);
+                }
+            }
+            ++a; ++b;
+        } else if (nodes1[a] < nodes2[b]) {
+            a = (int)(std::lower_bound(nodes1, nodes1 + nn1, nodes2[b]) - nodes1);
+        } else {
+            b = (int)(std::lower_bound(nodes2, nodes2 + nn2, nodes1[a]) - nodes2);
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int bb = 0; bb < HISTO_LENGTH; ++bb) {
+            if (bb == ind[0] || bb == ind[1] || bb == ind[2]) continue;
+            for (int i : rh.bins[bb]) { vbMatched2[vMatches12[i]] = false; vMatches12[i] = -1; nmatches--; }   // :1366
+        }
+    }
+    return nmatches;
+}
+
 int orbref_stereo_matches(const orbref_t* left, const orbref_t* right,
                           int N, const orbref_kp_t* kl, const uint8_t* dl, int Nr, const orbref_kp_t* kr, const uint8_t* dr,
                           float mb, float mbf, float* mvuRight, float* mvDepth) {

@@ -354,6 +354,9 @@ def _bind_search(L, prefix):
     g("search_for_triangulation").argtypes = h + [ci, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp, vp,
                                                   vp, cf, cf, vp, vp, ci, ci, ci, vp]
     g("search_by_bow").argtypes = h + [ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, cf, ci, vp]
+    g("search_for_triangulation_legacy").argtypes = g("search_for_triangulation").argtypes
+    g("search_by_projection_kf").argtypes = h + [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp]
+    g("search_by_bow_kf").argtypes = h + [ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, cf, ci, vp]
 
 
 class FrameView:
@@ -433,8 +436,27 @@ class _SearchMixin:
         n = self._call("search_for_initialization", C.byref(c1), C.byref(c2), _p(prev), int(window), float(nnratio), int(check_ori), _p(m12))
         return n, m12, prev
 
+    def SearchByProjectionKF(self, cur, blocked, scale_factors, valid, u, v, level, angle, qdesc, th, orb_dist, check_ori=True):
+        match = np.full(cur.n, -1, np.int32)
+        cs = cur.cstruct()
+        arr = [np.ascontiguousarray(a, t) for a, t in ((blocked, np.uint8), (scale_factors, np.float32), (valid, np.uint8),
+               (u, np.float32), (v, np.float32), (level, np.int32), (angle, np.float32), (qdesc, np.uint8))]
+        n = self._call("search_by_projection_kf", C.byref(cs), _p(arr[0]), _p(arr[1]), len(arr[2]), *[_p(a) for a in arr[2:]],
+                       float(th), int(orb_dist), int(check_ori), _p(match))
+        return n, match
+
+    def SearchByBoWKF(self, k1, d1, good1, fv1, k2, d2, good2, fv2, nnratio, check_ori=True):
+        m12 = np.full(len(k1), -1, np.int32)
+        k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)
+        d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        g1 = np.ascontiguousarray(good1, np.uint8); g2 = np.ascontiguousarray(good2, np.uint8)
+        n = self._call("search_by_bow_kf", len(k1), _p(k1), _p(d1), _p(g1), len(fv1[0]), _p(fv1[0]), _p(fv1[1]), _p(fv1[2]),
+                       len(k2), _p(k2), _p(d2), _p(g2), len(fv2[0]), _p(fv2[0]), _p(fv2[1]), _p(fv2[2]),
+                       float(nnratio), int(check_ori), _p(m12))
+        return n, m12
+
     def SearchForTriangulation(self, k1, d1, has_mp1, ur1, fv1, k2, d2, has_mp2, ur2, fv2, F12, ep, sf2, sigma2_2,
-                               only_stereo=False, coarse=False, check_ori=False):
+                               only_stereo=False, coarse=False, check_ori=False, legacy=False):
         m12 = np.full(len(k1), -1, np.int32)
         k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)
         d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
@@ -443,7 +465,7 @@ class _SearchMixin:
         u2 = None if ur2 is None else np.ascontiguousarray(ur2, np.float32)
         F = np.ascontiguousarray(F12, np.float32).reshape(9); sf2 = np.ascontiguousarray(sf2, np.float32)
         sg = np.ascontiguousarray(sigma2_2, np.float32)
-        n = self._call("search_for_triangulation", len(k1), _p(k1), _p(d1), _p(h1), None if u1 is None else _p(u1),
+        n = self._call("search_for_triangulation_legacy" if legacy else "search_for_triangulation", len(k1), _p(k1), _p(d1), _p(h1), None if u1 is None else _p(u1),
                        len(fv1[0]), _p(fv1[0]), _p(fv1[1]), _p(fv1[2]),
                        len(k2), _p(k2), _p(d2), _p(h2), None if u2 is None else _p(u2),
                        len(fv2[0]), _p(fv2[0]), _p(fv2[1]), _p(fv2[2]),
@@ -468,7 +490,7 @@ def _install_search():
     L.orbm_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     for name in ("grid_build", "SearchByProjectionFrame", "SearchByProjectionPoints", "SearchForInitialization",
-                 "SearchForTriangulation", "SearchByBoW", "_call"):
+                 "SearchForTriangulation", "SearchByBoW", "SearchByProjectionKF", "SearchByBoWKF", "_call"):
         setattr(ORBmatcher, name, getattr(_SearchMixin, name))
     ORBmatcher._prefix = "orbm_"
 
@@ -498,7 +520,8 @@ def _install_search():
 
 
 EXPORTS += ["orbm_grid_build", "orbm_window_candidates", "orbm_search_by_projection_frame", "orbm_search_by_projection_points",
-            "orbm_search_for_initialization", "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_stereo_matches"]
+            "orbm_search_for_initialization", "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_stereo_matches",
+            "orbm_search_by_projection_kf", "orbm_search_by_bow_kf", "orbm_search_for_triangulation_legacy"]
 _orig_lib = lib
 _search_ready = False
 

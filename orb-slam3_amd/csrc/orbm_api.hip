@@ -442,13 +442,14 @@ static void join_nodes(int nn1, const int32_t* nodes1, const int32_t* start1, co
     }
 }
 
-int orbm_search_for_triangulation(orbm_t* m, int n1, const orbm_kp_t* kps1, const uint8_t* desc1, const uint8_t* has_mp1, const float* uright1,
+static int triangulation_impl(orbm_t* m, bool legacy, int n1, const orbm_kp_t* kps1, const uint8_t* desc1, const uint8_t* has_mp1, const float* uright1,
                                   int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
                                   int n2, const orbm_kp_t* kps2, const uint8_t* desc2, const uint8_t* has_mp2, const float* uright2,
                                   int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2,
                                   const float* F12, float epx, float epy, const float* sf2, const float* sigma2_2,
                                   int bOnlyStereo, int bCoarse, int check_ori, int32_t* vMatches12) {
     if (!m || n1 < 0 || n2 < 0) return ORBM_E_INVALID;
+    std::vector<uint8_t> vbMatched2(n2, 0);                                 // only maintained by the legacy overload (:1319)
     JoinJobs J;
     join_nodes(nn1, nodes1, start1, idx1, nn2, nodes2, start2, J);
     std::vector<int> dist;
@@ -457,7 +458,7 @@ int orbm_search_for_triangulation(orbm_t* m, int n1, const orbm_kp_t* kps1, cons
     for (int i = 0; i < n1; ++i) vMatches12[i] = -1;
     int nmatches = 0;
     RotHist rh;
-    const float factor = 1.0f / ORBM_HISTO_LENGTH;                          // :1441 (sic)
+    const float factor = legacy ? ORBM_HISTO_LENGTH / 360.0f : 1.0f / ORBM_HISTO_LENGTH;   // :1166 vs :1441 (sic)
     for (size_t j = 0; j < J.q.size(); ++j) {
         const int i1 = J.q[j];
         if (has_mp1[i1]) continue;
@@ -467,7 +468,7 @@ int orbm_search_for_triangulation(orbm_t* m, int n1, const orbm_kp_t* kps1, cons
         int bestDist = ORBM_TH_LOW, bestIdx2 = -1;
         for (int c = 0; c < J.len[j]; ++c) {
             const int i2 = idx2[J.l2[j] + c];
-            if (has_mp2[i2]) continue;
+            if (vbMatched2[i2] || has_mp2[i2]) continue;
             const bool bStereo2 = uright2 && uright2[i2] >= 0;
             if (bOnlyStereo && !bStereo2) continue;
             const int d = dist[J.off[j] + c];
@@ -490,6 +491,7 @@ int orbm_search_for_triangulation(orbm_t* m, int n1, const orbm_kp_t* kps1, cons
         }
         if (bestIdx2 >= 0) {
             vMatches12[i1] = bestIdx2;
+            if (legacy) vbMatched2[bestIdx2] = 1;
             nmatches++;
             if (check_ori) rh.add(kp1.angle, kps2[bestIdx2].angle, factor, i1);
         }
@@ -499,7 +501,117 @@ int orbm_search_for_triangulation(orbm_t* m, int n1, const orbm_kp_t* kps1, cons
         rh.maxima(ind);
         for (int b = 0; b < ORBM_HISTO_LENGTH; ++b) {
             if (b == ind[0] || b == ind[1] || b == ind[2]) continue;
-            for (int i : rh.bins[b]) { vMatches12[i] = -1; nmatches--; }
+            for (int i : rh.bins[b]) { if (legacy) vbMatched2[vMatches12[i]] = 0; vMatches12[i] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+int orbm_search_for_triangulation(orbm_t* m, int n1, const orbm_kp_t* kps1, const uint8_t* desc1, const uint8_t* has_mp1, const float* uright1,
+                                  int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
+                                  int n2, const orbm_kp_t* kps2, const uint8_t* desc2, const uint8_t* has_mp2, const float* uright2,
+                                  int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2,
+                                  const float* F12, float epx, float epy, const float* sf2, const float* sigma2_2,
+                                  int bOnlyStereo, int bCoarse, int check_ori, int32_t* vMatches12) {
+    return triangulation_impl(m, false, n1, kps1, desc1, has_mp1, uright1, nn1, nodes1, start1, idx1, n2, kps2, desc2, has_mp2, uright2,
+                              nn2, nodes2, start2, idx2, F12, epx, epy, sf2, sigma2_2, bOnlyStereo, bCoarse, check_ori, vMatches12);
+}
+
+int orbm_search_for_triangulation_legacy(orbm_t* m, int n1, const orbm_kp_t* kps1, const uint8_t* desc1, const uint8_t* has_mp1, const float* uright1,
+                                  int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
+                                  int n2, const orbm_kp_t* kps2, const uint8_t* desc2, const uint8_t* has_mp2, const float* uright2,
+                                  int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2,
+                                  const float* F12, float epx, float epy, const float* sf2, const float* sigma2_2,
+                                  int bOnlyStereo, int bCoarse, int check_ori, int32_t* vMatches12) {
+    return triangulation_impl(m, true, n1, kps1, desc1, has_mp1, uright1, nn1, nodes1, start1, idx1, n2, kps2, desc2, has_mp2, uright2,
+                              nn2, nodes2, start2, idx2, F12, epx, epy, sf2, sigma2_2, bOnlyStereo, bCoarse, check_ori, vMatches12);
+}
+
+int orbm_search_by_projection_kf(orbm_t* m, const orbm_frame_t* cur, const uint8_t* blocked_in, const float* sf,
+                                 int nq, const uint8_t* valid, const float* u, const float* v, const int32_t* level,
+                                 const float* angle, const uint8_t* qdesc, float th, int ORBdist, int check_ori, int32_t* match) {
+    if (!m || !cur || nq < 0) return ORBM_E_INVALID;
+    std::vector<float> qr(nq);
+    std::vector<int> minl(nq), maxl(nq);
+    for (int i = 0; i < nq; ++i) {
+        if (!valid[i]) { qr[i] = -1.f; minl[i] = 0; maxl[i] = -1; continue; }
+        qr[i] = th * sf[level[i]]; minl[i] = level[i] - 1; maxl[i] = level[i] + 1;      // :2775-2778
+    }
+    const int cap = std::max(1, std::min(cur->n, 2048));
+    std::vector<int> cnt, idx, dist;
+    orbm_frame_t f = *cur; f.uright = nullptr;                              // this overload has no stereo gate
+    int rc = window_pass(m, &f, nq, u, v, qr.data(), minl.data(), maxl.data(), nullptr, nullptr, qdesc, cap, cnt, idx, dist);
+    if (rc) return rc;
+    int nmatches = 0;
+    RotHist rh;
+    const float factor = ORBM_HISTO_LENGTH / 360.0f;                        // :2736
+    std::vector<uint8_t> taken(blocked_in, blocked_in + cur->n);
+    for (int i = 0; i < cur->n; ++i) match[i] = -1;
+    for (int i = 0; i < nq; ++i) {
+        if (!valid[i] || cnt[i] == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < cnt[i]; ++c) {
+            const int i2 = idx[(size_t)i * cap + c];
+            if (taken[i2]) continue;                                        // :2793
+            const int d = dist[(size_t)i * cap + c];
+            if (d < bestDist) { bestDist = d; bestIdx2 = i2; }
+        }
+        if (bestDist <= ORBdist) {
+            match[bestIdx2] = i; taken[bestIdx2] = 1;
+            nmatches++;
+            if (check_ori) rh.add(angle[i], cur->kps[bestIdx2].angle, factor, bestIdx2);
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int b = 0; b < ORBM_HISTO_LENGTH; ++b)
+            if (b != ind[0] && b != ind[1] && b != ind[2])
+                for (int k : rh.bins[b]) { match[k] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
+int orbm_search_by_bow_kf(orbm_t* m, int n1, const orbm_kp_t* kps1, const uint8_t* desc1, const uint8_t* good1,
+                          int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
+                          int n2, const orbm_kp_t* kps2, const uint8_t* desc2, const uint8_t* good2,
+                          int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2,
+                          float nnratio, int check_ori, int32_t* vpMatches12) {
+    if (!m || n1 < 0 || n2 < 0) return ORBM_E_INVALID;
+    JoinJobs J;
+    join_nodes(nn1, nodes1, start1, idx1, nn2, nodes2, start2, J);
+    std::vector<int> dist;
+    int rc = bucket_pass(m, desc1, n1, desc2, n2, idx2, start2[nn2], J, dist);
+    if (rc) return rc;
+    for (int i = 0; i < n1; ++i) vpMatches12[i] = -1;
+    std::vector<uint8_t> vbMatched2(n2, 0);
+    int nmatches = 0;
+    RotHist rh;
+    const float factor = ORBM_HISTO_LENGTH / 360.0f;                        // :978
+    for (size_t j = 0; j < J.q.size(); ++j) {
+        const int i1 = J.q[j];
+        if (!good1[i1]) continue;
+        int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+        for (int c = 0; c < J.len[j]; ++c) {
+            const int i2 = idx2[J.l2[j] + c];
+            if (vbMatched2[i2] || !good2[i2]) continue;
+            const int d = dist[J.off[j] + c];
+            if (d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdx2 = i2; }
+            else if (d < bestDist2) bestDist2 = d;
+        }
+        if (bestDist1 < ORBM_TH_LOW && static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+            vpMatches12[i1] = bestIdx2;
+            vbMatched2[bestIdx2] = 1;
+            if (check_ori) rh.add(kps1[i1].angle, kps2[bestIdx2].angle, factor, i1);
+            nmatches++;
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int b = 0; b < ORBM_HISTO_LENGTH; ++b) {
+            if (b == ind[0] || b == ind[1] || b == ind[2]) continue;
+            for (int i : rh.bins[b]) { vpMatches12[i] = -1; nmatches--; }
         }
     }
     return nmatches;

@@ -140,6 +140,49 @@ def test_search_by_bow(pkg, scene, bits, nnratio, ori):
     assert n_gpu == n_ref and np.array_equal(m_gpu, m_ref)
 
 
+@pytest.mark.parametrize("th,orb_dist,ori", [(10, 100, True), (3, 64, True), (10, 100, False)])
+def test_search_by_projection_kf(pkg, scene, th, orb_dist, ori):
+    # relocalisation refinement: Tracking.cc:4309 (th=10, ORBdist=100) and :4334 (th=3, ORBdist=64)
+    rng = np.random.default_rng(th + orb_dist)
+    kr = scene["kr"]
+    views = [pkg.FrameView(kr, scene["dr"], 752, 480, backend=b) for b in (scene["m"], scene["OM"])]
+    n, u, v = _queries(scene, rng)
+    lvl = np.clip(scene["kl"]["octave"] + rng.integers(-1, 2, n), 0, 7)
+    args = dict(blocked=rng.random(len(kr)) < 0.2, scale_factors=scene["sf"], valid=rng.random(n) < 0.7, u=u, v=v, level=lvl,
+                angle=scene["kl"]["angle"], qdesc=scene["dl"], th=th, orb_dist=orb_dist, check_ori=ori)
+    n_gpu, m_gpu = scene["m"].SearchByProjectionKF(views[0], **args)
+    n_ref, m_ref = scene["OM"].SearchByProjectionKF(views[1], **args)
+    assert n_gpu == n_ref and np.array_equal(m_gpu, m_ref) and n_ref > 20
+
+
+@pytest.mark.parametrize("bits,nnratio,ori", [(6, 0.75, True), (3, 0.9, True), (8, 0.75, False)])
+def test_search_by_bow_kf(pkg, scene, bits, nnratio, ori):
+    rng = np.random.default_rng(bits + 300)
+    kl, kr, dl, dr = scene["kl"], scene["kr"], scene["dl"], scene["dr"]
+    args = dict(k1=kl, d1=dl, good1=rng.random(len(kl)) < 0.8, fv1=_fv(pkg, dl, bits), k2=kr, d2=dr,
+                good2=rng.random(len(kr)) < 0.8, fv2=_fv(pkg, dr, bits), nnratio=nnratio, check_ori=ori)
+    n_gpu, m_gpu = scene["m"].SearchByBoWKF(**args)
+    n_ref, m_ref = scene["OM"].SearchByBoWKF(**args)
+    assert n_gpu == n_ref and np.array_equal(m_gpu, m_ref)
+
+
+@pytest.mark.parametrize("bits,coarse,ori", [(5, True, True), (6, False, True), (4, True, False)])
+def test_search_for_triangulation_legacy(pkg, scene, bits, coarse, ori):
+    rng = np.random.default_rng(bits + 500)
+    kl, kr, dl, dr = scene["kl"], scene["kr"], scene["dl"], scene["dr"]
+    F12 = np.array([[1e-7, -3e-6, 1.1e-3], [2.5e-6, 2e-7, -0.0231], [-1.3e-3, 0.0229, 0.35]], np.float32)
+    args = dict(k1=kl, d1=dl, has_mp1=rng.random(len(kl)) < 0.3, ur1=np.where(rng.random(len(kl)) < 0.5, 5.0, -1.0),
+                fv1=_fv(pkg, dl, bits), k2=kr, d2=dr, has_mp2=rng.random(len(kr)) < 0.3,
+                ur2=np.where(rng.random(len(kr)) < 0.5, 5.0, -1.0), fv2=_fv(pkg, dr, bits), F12=F12, ep=(900.0, 240.0),
+                sf2=scene["sf"], sigma2_2=scene["sigma2"], only_stereo=False, coarse=coarse, check_ori=ori, legacy=True)
+    n_gpu, m_gpu = scene["m"].SearchForTriangulation(**args)
+    n_ref, m_ref = scene["OM"].SearchForTriangulation(**args)
+    assert n_gpu == n_ref and np.array_equal(m_gpu, m_ref)
+    if coarse:
+        taken = m_ref[m_ref >= 0]
+        assert len(np.unique(taken)) == len(taken)          # vbMatched2 keeps the matching one-to-one
+
+
 def test_compute_stereo_matches(pkg, scene):
     # EuRoC stereo: bf = 47.906, fx = 435.2 -> mb = bf/fx (Examples/Stereo/EuRoC.yaml:9,28)
     mbf = 47.90639384423901; mb = mbf / 435.2046959714599
