@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic frames generated per rank")
+    ap.add_argument("--handles", type=int, default=1, help="extractor handles kept in flight per GPU (the batch is split over them)")
     ap.add_argument("--cpu-sample", type=int, default=96, help="frames timed through the CPU oracle (0 = skip)")
     args = ap.parse_args()
 
@@ -59,8 +60,14 @@ def main():
     L = pkg.lib()
 
     W, H, B = args.width, args.height, args.batch
-    ex = pkg.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local_rank, max_size=(W, H), max_batch=B)
-    mt = pkg.ORBmatcher(0.7, device=local_rank)
+    # The batch of B frames is split over `--handles` extractor handles (own streams + scratch each) that are kept in
+    # flight together: while one half-batch is in its latency-bound quadtree/descriptor kernels the other one runs the
+    # VALU-bound FAST kernel.  No host sync inside a step: matcher streams wait on extractor streams through events.
+    NH = max(1, min(args.handles, B))
+    sizes = [B // NH + (1 if i < B % NH else 0) for i in range(NH)]
+    exs = [pkg.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local_rank, max_size=(W, H), max_batch=sz) for sz in sizes]
+    mts = [pkg.ORBmatcher(0.7, device=local_rank) for _ in range(NH)]
+    ex = exs[0]
     cap = ex.cap
 
     # ---- inputs resident in HBM before the timed region
@@ -71,22 +78,43 @@ def main():
     for i in range(B):
         padded[:, :W] = host_imgs[i % len(host_imgs)]
         dev.upload(padded, offset=i * stride * H)
-    ptrs = (C.c_void_p * B)(*[dev.ptr + i * stride * H for i in range(B)])
-    lap = np.tile(np.array([0, 1000], np.int32), B)       # monocular call: vLapping = {0,1000} (Frame.cc:361)
-
-    res = ex.result_device()
-    idx2 = pkg.DeviceBuffer(B * cap * 2 * 4)
-    dist2 = pkg.DeviceBuffer(B * cap * 2 * 4)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+    ptrs = [(C.c_void_p * sizes[h])(*[int(dev.ptr + int(offs[h] + i) * stride * H) for i in range(sizes[h])]) for h in range(NH)]
+    laps = [np.tile(np.array([0, 1000], np.int32), sizes[h]) for h in range(NH)]   # monocular call: vLapping = {0,1000} (Frame.cc:361)
+    res = [e.result_device() for e in exs]
+    idx2 = [pkg.DeviceBuffer(max(1, sizes[h]) * cap * 2 * 4) for h in range(NH)]
+    dist2 = [pkg.DeviceBuffer(max(1, sizes[h]) * cap * 2 * 4) for h in range(NH)]
+    xidx = pkg.DeviceBuffer(NH * cap * 2 * 4); xdist = pkg.DeviceBuffer(NH * cap * 2 * 4)
 
     def step():
-        ex.enqueue_device(ptrs, W, H, stride, lap)
-        # match frame i (query) against frame i-1 (train); frame 0 against frame B-1 of the same batch.
-        # Both kernels run on their own streams: order them with a sync-free event-less handoff by syncing
-        # the extractor stream first (cheap vs the step; keeps the result buffers coherent).
-        ex.sync()
-        rc = L.orbm_knn2_batch_async(mt.h, res["desc"] + cap * 32, cap, res["counts"] + 4, res["desc"], cap,
-                                     res["counts"], B - 1, cap, idx2.ptr + cap * 8, dist2.ptr + cap * 8)
-        assert rc == 0, rc
+        for h in range(NH):
+            # the next batch may overwrite result buffers the matcher of the previous step still reads
+            L.orbx_stream_wait_other(exs[h].h, L.orbm_stream(mts[h].h))
+            if h > 0:
+                L.orbx_stream_wait_other(exs[h].h, L.orbm_stream(mts[h - 1].h))
+            exs[h].enqueue_device(ptrs[h], W, H, stride, laps[h])
+        for h in range(NH):
+            ms = L.orbm_stream(mts[h].h)
+            L.orbx_stream_wait_results(exs[h].h, ms)
+            r = res[h]
+            # dense 2-NN Hamming match of frame i (query) against frame i-1 (train) inside the half-batch ...
+            if sizes[h] > 1:
+                rc = L.orbm_knn2_batch_async(mts[h].h, r["desc"] + cap * 32, cap, r["counts"] + 4, r["desc"], cap, r["counts"],
+                                             sizes[h] - 1, cap, idx2[h].ptr + cap * 8, dist2[h].ptr + cap * 8)
+                assert rc == 0, rc
+            # ... and of its first frame against the last frame of the previous half-batch (B-1 pairs in total)
+            if h > 0:
+                L.orbx_stream_wait_results(exs[h - 1].h, ms)
+                p = res[h - 1]
+                rc = L.orbm_knn2_batch_async(mts[h].h, r["desc"], cap, r["counts"], p["desc"] + (sizes[h - 1] - 1) * cap * 32, cap,
+                                             p["counts"] + 4 * (sizes[h - 1] - 1), 1, cap, xidx.ptr + h * cap * 8, xdist.ptr + h * cap * 8)
+                assert rc == 0, rc
+
+    def sync_all():
+        for e in exs:
+            e.sync()
+        for m in mts:
+            m.sync()
 
     def barrier():
         if world > 1:
@@ -95,21 +123,28 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    mt.sync()
-    t_pyr, t_fast, t_all = [], [], []
+    sync_all()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        tm = ex.timings()                                  # HIP events on the extractor's own stream
-        t_pyr.append(tm["pyramid_fast_span"]); t_fast.append(0.0); t_all.append(tm)
-    mt.sync()
+    sync_all()
     barrier()
     dt = time.perf_counter() - t0
 
-    counts = ex.result_device()
+    # HIP-event kernel times of the timed steps (events recorded on the streams the kernels were launched on)
+    t_all = []
+    for e, sz in zip(exs, sizes):
+        tm, ns = e.mean_timings()
+        t_all.append((tm, sz))
+    t_pyr = [sum(tm["pyramid_fast_span"] for tm, _ in t_all) / len(t_all)]
+    t_fast = [0.0]
+    mt = mts[0]
     n_host = np.zeros(B, np.int32)                         # keypoint counts of the last batch
-    L.orbx_memcpy_d2h(n_host.ctypes.data_as(C.c_void_p), counts["counts"], 4 * B)
+    for h in range(NH):
+        part = np.zeros(sizes[h], np.int32)
+        L.orbx_memcpy_d2h(part.ctypes.data_as(C.c_void_p), res[h]["counts"], 4 * sizes[h])
+        n_host[offs[h]:offs[h + 1]] = part
     dmod = importlib.import_module("orb-slam3_amd.dist")
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -122,17 +157,19 @@ def main():
     if rank == 0:
         frames = B * args.steps * world
         alg, fused = ex.algorithmic_bytes()
+        # every handle processes its share of the batch concurrently: per-launch-group figure = bytes of ONE handle's
+        # frames / that handle's own pyramid+FAST wall span (conservative: the spans overlap other handles' kernels)
         pf_ms = float(np.mean(t_pyr) + np.mean(t_fast))
-        achieved = alg * B / (pf_ms * 1e-3) / 1e9
+        achieved = alg * (B / NH) / (pf_ms * 1e-3) / 1e9
         traffic = None                                      # HBM bytes/launch-group from the committed rocprofv3 --pmc passes
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             c = tj["config"]
             if (c["width"], c["height"], c["nfeatures"]) == (W, H, args.nfeatures):
-                traffic = tj["pyramid_fast_bytes_per_frame"] * B
+                traffic = tj["pyramid_fast_bytes_per_frame"] * (B / NH)
         except Exception:
             traffic = None
-        stage = {k: float(np.mean([t[k] for t in t_all])) for k in t_all[0]}
+        stage = {k: float(np.mean([tm[k] for tm, _ in t_all])) for k in t_all[0][0]}
         stage["knn2"] = mt.timing_ms()
         out = {
             "metric": "ORB extract+match frames/sec @752x480, 1000 feat",
@@ -142,10 +179,10 @@ def main():
             "config": {"workload": "configs[1]: %dx%d grayscale, %d features, 8 levels, scale 1.2, FAST 20/7; "
                                    "batch of %d frames/GPU/step resident in HBM; extract + dense 2-NN Hamming "
                                    "match against the previous frame" % (W, H, args.nfeatures, B),
-                       "frames_per_step_per_gpu": B, "keypoints_last_batch": int(total_kp.item())},
+                       "frames_per_step_per_gpu": B, "handles_in_flight": NH, "keypoints_last_batch": int(total_kp.item())},
             "roofline": {"bound": "hbm", "kernel": "pyramid+FAST pass (k_resize2 x7 on stream 2 + k_fast3 x2 on stream 1; wall span by HIP events)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg * B, "algorithmic_bytes_per_frame": alg, "fused_lower_bound_per_frame": fused,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg * (B / NH), "frames_per_launch": B / NH, "algorithmic_bytes_per_frame": alg, "fused_lower_bound_per_frame": fused,
                          "launch_ms": pf_ms},
             "stage_ms_per_step": stage,
         }

@@ -88,11 +88,17 @@ int orbx_level_selected(orbx_t*, int frame, int level, int32_t* xyr, int cap);
  * 5 orient+descriptor, 6 total, 7 wall span from the first resize/FAST launch to the end of the last FAST launch
  * (the two streams overlap, so 0+1 double-counts; 7 is the figure the roofline uses).  ms8 holds 8 floats. */
 int orbx_last_timings(orbx_t*, float* ms8);
+/* mean of the same 8 figures over the most recent (<= 32) enqueued batches; *nsamples = how many were averaged.
+ * Lets a caller keep enqueueing without a host sync per batch and still report HIP-event kernel times. */
+int orbx_mean_timings(orbx_t*, float* ms8, int* nsamples);
+/* stream ordering without host syncs: make `other_stream` (a hipStream_t, e.g. orbm_stream()) wait for everything
+ * enqueued so far on this extractor / make this extractor's next batch wait for `other_stream` (a consumer still
+ * reading the result buffers of the previous batch). */
+int orbx_stream_wait_results(orbx_t*, void* other_stream);
+int orbx_stream_wait_other(orbx_t*, void* other_stream);
 /* algorithmic bytes of the pyramid+FAST pass for one frame of the current geometry */
 int64_t orbx_algorithmic_bytes(const orbx_t*, int64_t* fused_lower_bound);
 void* orbx_stream(const orbx_t*);     /* hipStream_t the kernels are launched on */
-/* diagnostic builds only (-DORBX_STAMPS): accumulated per-phase cycle stamps of the FAST kernel; zeros otherwise */
-int orbx_debug_stamps(orbx_t*, unsigned long long* out, int n);
 
 /* plain device-memory helpers so callers need no HIP bindings of their own */
 void* orbx_dev_alloc(size_t bytes);

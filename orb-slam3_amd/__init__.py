@@ -27,7 +27,7 @@ EXPORTS = [
     "orbx_create", "orbx_destroy", "orbx_last_error", "orbx_max_keypoints", "orbx_extract", "orbx_extract_batch",
     "orbx_extract_batch_async", "orbx_sync", "orbx_result_device", "orbx_result_fetch", "orbx_level_size",
     "orbx_level_image", "orbx_scale_tables", "orbx_features_per_level", "orbx_level_candidates",
-    "orbx_level_selected", "orbx_last_timings", "orbx_algorithmic_bytes", "orbx_stream", "orbx_debug_stamps", "orbx_dev_alloc",
+    "orbx_level_selected", "orbx_last_timings", "orbx_mean_timings", "orbx_stream_wait_results", "orbx_stream_wait_other", "orbx_algorithmic_bytes", "orbx_stream", "orbx_dev_alloc",
     "orbx_dev_free", "orbx_memcpy_h2d", "orbx_memcpy_d2h", "orbx_device_count",
     # include/orbm.h
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_sync", "orbm_stream", "orbm_hamming",
@@ -72,7 +72,9 @@ def lib():
         L.orbx_last_timings.argtypes = [vp, vp]
         L.orbx_algorithmic_bytes.restype = C.c_int64
         L.orbx_algorithmic_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
-        L.orbx_debug_stamps.argtypes = [vp, vp, ci]
+        L.orbx_mean_timings.argtypes = [vp, vp, i32p]
+        L.orbx_stream_wait_results.argtypes = [vp, vp]
+        L.orbx_stream_wait_other.argtypes = [vp, vp]
         L.orbx_stream.restype = vp
         L.orbx_stream.argtypes = [vp]
         L.orbx_dev_alloc.restype = vp
@@ -268,6 +270,11 @@ class ORBextractor:
         t = np.zeros(8, np.float32)
         _chk(self.L.orbx_last_timings(self.h, _p(t)), "timings")
         return dict(zip(["pyramid", "fast", "quadtree", "slots", "blur", "orient_desc", "total", "pyramid_fast_span"], t.tolist()))
+
+    def mean_timings(self):
+        t = np.zeros(8, np.float32); n = C.c_int32()
+        _chk(self.L.orbx_mean_timings(self.h, _p(t), C.byref(n)), "mean_timings")
+        return dict(zip(["pyramid", "fast", "quadtree", "slots", "blur", "orient_desc", "total", "pyramid_fast_span"], t.tolist())), n.value
 
     def algorithmic_bytes(self):
         f = C.c_int64()

@@ -56,11 +56,15 @@ struct orbx {
     int64_t algBytes = 0, fusedBytes = 0;
     size_t qtLds = 0, qt2Lds = 0;
     int qt2Cap = 0, qt2Sort = 0;
-    bool qtV1 = false, odV1 = false;
+    bool qtV1 = false, odV1 = false, serial = false;
     // device
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;
-    hipEvent_t ev[12] = {};
+    static const int kRing = 32;                             // timing-event sets kept for orbx_mean_timings
+    hipEvent_t evr[kRing][12] = {};
+    hipEvent_t* ev = evr[0];
+    hipEvent_t evDone = nullptr;
+    long nEnq = 0;
     int nStrips0 = 0;
     u8 *dPyr = nullptr, *dBlur = nullptr, *dL0 = nullptr;
     const u8** dL0Ptr = nullptr;
@@ -72,7 +76,6 @@ struct orbx {
     KpOut* dKps = nullptr; u8* dDesc = nullptr; KpWork* dWork = nullptr;
     int *dN = nullptr, *dMono = nullptr, *dLap = nullptr, *dErr = nullptr;
     int8_t* dPattern = nullptr;
-    unsigned long long* dStamps = nullptr;
     size_t capL0 = 0, capPyr = 0, capCells = 0, capTiles = 0, capXt = 0, capYt = 0, capCandCnt = 0, capCandEnt = 0, capSel = 0;
     int lastBatch = 0;
     int l0pitch = 0, lastL0Pitch = 0;
@@ -346,7 +349,8 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     o->maxW = max_w; o->maxH = max_h; o->maxBatch = max_batch;
     o->fastV1 = getenv("ORBX_FAST_V1") != nullptr;
     o->qtV1 = getenv("ORBX_QT_V1") != nullptr;
-    o->odV1 = getenv("ORBX_OD_V1") != nullptr;            // A/B switch: simple per-cell reference kernel
+    o->odV1 = getenv("ORBX_OD_V1") != nullptr;
+    o->serial = getenv("ORBX_SERIAL") != nullptr;            // A/B switch: simple per-cell reference kernel
     o->scaleFactor = scale_factor;                              // double member initialised from float (ORBextractor.h:96)
     const int L = nlevels;
     o->sf.resize(L); o->sig2.resize(L); o->invsf.resize(L); o->invsig2.resize(L); o->nfeat.resize(L);
@@ -367,13 +371,14 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     int rc = ORBX_OK;
     do {
         if (hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&o->stream2, hipStreamNonBlocking) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipStreamCreate failed"); break; }
-        for (auto& e : o->ev) if (hipEventCreate(&e) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); break; }
+        for (auto& set : o->evr) for (auto& e : set) if (rc == ORBX_OK && hipEventCreate(&e) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
+        if (rc == ORBX_OK && hipEventCreateWithFlags(&o->evDone, hipEventDisableTiming) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
         if (rc) break;
         const size_t B = max_batch;
         if (hipMalloc((void**)&o->dL0Ptr, sizeof(u8*) * B) != hipSuccess || hipMalloc((void**)&o->dSelCnt, sizeof(u32) * 12 * B) != hipSuccess ||
             hipMalloc((void**)&o->dN, sizeof(int) * B) != hipSuccess || hipMalloc((void**)&o->dMono, sizeof(int) * B) != hipSuccess ||
             hipMalloc((void**)&o->dLap, sizeof(int) * 2 * B) != hipSuccess || hipMalloc((void**)&o->dErr, sizeof(int)) != hipSuccess ||
-            hipMalloc((void**)&o->dPattern, 1024) != hipSuccess || hipMalloc((void**)&o->dStamps, 64 * 8) != hipSuccess || hipMemset(o->dStamps, 0, 64 * 8) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
+            hipMalloc((void**)&o->dPattern, 1024) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
         if (hipMemcpy(o->dPattern, kPattern, 1024, hipMemcpyHostToDevice) != hipSuccess || hipMemset(o->dErr, 0, sizeof(int)) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMemcpy failed"); break; }
         o->hL0Ptr.resize(B); o->hLap.resize(2 * B);
         rc = build_geometry(o, max_w, max_h);
@@ -389,9 +394,10 @@ void orbx_destroy(orbx_t* o) {
     if (o->stream) (void)hipStreamSynchronize(o->stream);
     if (o->stream2) (void)hipStreamSynchronize(o->stream2);
     void* ptrs[] = {o->dPyr, o->dBlur, o->dL0, (void*)o->dL0Ptr, o->dCells, o->dTiles, o->dStrips, o->dX4, o->dRzTasks, o->dXt, o->dYt, o->dCandCnt, o->dCandEnt,
-                    o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->dKps, o->dDesc, o->dWork, o->dN, o->dMono, o->dLap, o->dErr, o->dPattern, o->dStamps};
+                    o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->dKps, o->dDesc, o->dWork, o->dN, o->dMono, o->dLap, o->dErr, o->dPattern};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (auto& e : o->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& set : o->evr) for (auto& e : set) if (e) (void)hipEventDestroy(e);
+    if (o->evDone) (void)hipEventDestroy(o->evDone);
     if (o->stream) (void)hipStreamDestroy(o->stream);
     if (o->stream2) (void)hipStreamDestroy(o->stream2);
     delete o;
@@ -437,11 +443,13 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     HIPCHK(hipMemcpyAsync(o->dLap, o->hLap.data(), sizeof(int) * 2 * nimg, hipMemcpyHostToDevice, st));
 
     o->lastL0Pitch = l0pitch;
+    o->ev = o->evr[o->nEnq % orbx::kRing];
+    ++o->nEnq;
     // Two HIP streams (events order them): the resize chain + blur are latency-bound and leave the VALUs idle, FAST is
     // VALU-bound -- so level-0 FAST (needs no resize) runs beside the resize chain and levels 1..7 beside the blur.
     //   s0: FAST(L0) --wait pyramid--> FAST(L1..) -> quadtree -> slots --wait blur--> orientation+descriptors
     //   s1: resize L1..L7 -> [pyramid ready] -> blur -> [blur ready]
-    hipStream_t s1 = o->stream2;
+    hipStream_t s1 = o->serial ? o->stream : o->stream2;          // ORBX_SERIAL=1: single stream, clean per-kernel timings
     HIPCHK(hipEventRecord(o->ev[0], st));
     HIPCHK(hipStreamWaitEvent(s1, o->ev[0], 0));                 // inputs uploaded; previous batch's readers of the pyramid are done
     HIPCHK(hipEventRecord(o->ev[7], s1));
@@ -637,22 +645,60 @@ int orbx_level_selected(orbx_t* o, int frame, int level, int32_t* xyr, int cap) 
     return (int)n;
 }
 
+static int timings_of(orbx* o, hipEvent_t* ev, float* ms7) {
+    float f0 = 0, f1 = 0;
+    HIPCHK(hipEventElapsedTime(&ms7[0], ev[7], ev[8]));      // resize chain (stream 2)
+    HIPCHK(hipEventElapsedTime(&f0, ev[0], ev[10]));         // FAST level 0 (fastV1: whole FAST is ev1->ev10)
+    HIPCHK(hipEventElapsedTime(&f1, ev[1], o->fastV1 ? ev[10] : ev[2]));
+    ms7[1] = o->fastV1 ? f1 : f0 + f1;
+    HIPCHK(hipEventElapsedTime(&ms7[2], ev[2], ev[3]));
+    HIPCHK(hipEventElapsedTime(&ms7[3], ev[3], ev[4]));
+    HIPCHK(hipEventElapsedTime(&ms7[4], ev[8], ev[9]));      // blur (stream 2)
+    HIPCHK(hipEventElapsedTime(&ms7[5], ev[5], ev[6]));
+    HIPCHK(hipEventElapsedTime(&ms7[6], ev[0], ev[6]));
+    HIPCHK(hipEventElapsedTime(&ms7[7], ev[0], ev[2]));      // wall span of the pyramid+FAST pass (both streams)
+    return ORBX_OK;
+}
+
 int orbx_last_timings(orbx_t* o, float* ms7) {   // 8 floats, see include/orbx.h
     if (!o || !o->timed) return ORBX_E_INVALID;
     HIPCHK(hipSetDevice(o->device));
     HIPCHK(hipStreamSynchronize(o->stream));
     HIPCHK(hipStreamSynchronize(o->stream2));
-    float f0 = 0, f1 = 0;
-    HIPCHK(hipEventElapsedTime(&ms7[0], o->ev[7], o->ev[8]));      // resize chain (stream 2)
-    HIPCHK(hipEventElapsedTime(&f0, o->ev[0], o->ev[10]));         // FAST level 0 (fastV1: whole FAST is ev1->ev10)
-    HIPCHK(hipEventElapsedTime(&f1, o->ev[1], o->fastV1 ? o->ev[10] : o->ev[2]));
-    ms7[1] = o->fastV1 ? f1 : f0 + f1;
-    HIPCHK(hipEventElapsedTime(&ms7[2], o->ev[2], o->ev[3]));
-    HIPCHK(hipEventElapsedTime(&ms7[3], o->ev[3], o->ev[4]));
-    HIPCHK(hipEventElapsedTime(&ms7[4], o->ev[8], o->ev[9]));      // blur (stream 2)
-    HIPCHK(hipEventElapsedTime(&ms7[5], o->ev[5], o->ev[6]));
-    HIPCHK(hipEventElapsedTime(&ms7[6], o->ev[0], o->ev[6]));
-    HIPCHK(hipEventElapsedTime(&ms7[7], o->ev[0], o->ev[2]));      // wall span of the pyramid+FAST pass (both streams)
+    return timings_of(o, o->ev, ms7);
+}
+
+int orbx_mean_timings(orbx_t* o, float* ms8, int* nsamples) {
+    if (!o || !o->timed) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    HIPCHK(hipStreamSynchronize(o->stream));
+    HIPCHK(hipStreamSynchronize(o->stream2));
+    const int n = (int)std::min<long>(o->nEnq, orbx::kRing);
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < n; ++k) {
+        float t[8];
+        int rc = timings_of(o, o->evr[(o->nEnq - 1 - k) % orbx::kRing], t);
+        if (rc) return rc;
+        for (int i = 0; i < 8; ++i) acc[i] += t[i];
+    }
+    for (int i = 0; i < 8; ++i) ms8[i] = n ? (float)(acc[i] / n) : 0.f;
+    if (nsamples) *nsamples = n;
+    return ORBX_OK;
+}
+
+int orbx_stream_wait_results(orbx_t* o, void* other_stream) {
+    if (!o) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    HIPCHK(hipEventRecord(o->evDone, o->stream));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)other_stream, o->evDone, 0));
+    return ORBX_OK;
+}
+
+int orbx_stream_wait_other(orbx_t* o, void* other_stream) {
+    if (!o) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    HIPCHK(hipEventRecord(o->evDone, (hipStream_t)other_stream));
+    HIPCHK(hipStreamWaitEvent(o->stream, o->evDone, 0));
     return ORBX_OK;
 }
 
@@ -660,15 +706,6 @@ int64_t orbx_algorithmic_bytes(const orbx_t* o, int64_t* fused_lower_bound) {
     if (!o) return ORBX_E_INVALID;
     if (fused_lower_bound) *fused_lower_bound = o->fusedBytes;
     return o->algBytes;
-}
-
-int orbx_debug_stamps(orbx_t* o, unsigned long long* out, int n) {
-    if (!o || n > 64) return ORBX_E_INVALID;
-    HIPCHK(hipSetDevice(o->device));
-    HIPCHK(hipStreamSynchronize(o->stream));
-    HIPCHK(hipMemcpy(out, o->dStamps, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(o->dStamps, 0, 64 * 8));
-    return ORBX_OK;
 }
 
 // internal (not part of include/orbx.h): device pointers of the pyramid levels of batch slot `frame`, used by the

@@ -361,53 +361,77 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
         const int vy0 = 3, vy1 = H - 3;
         int n3 = 0;
         if (cx1 > cx0 && vy1 > vy0) {
-            const int gx0 = cx0 >> 2, ng = ((cx1 + 3) >> 2) - gx0, total = ng * (vy1 - vy0);
-            const float inv = 1.0f / (float)ng;
+            // lane -> (row offset lr, 8-px column lc): ncol columns cover [cx0, cx1), rpi rows per wave-iteration
+            const int c80 = cx0 >> 3, ncol = ((cx1 + 7) >> 3) - c80, nrow = vy1 - vy0;
+            int rpi = 1;
+            while ((rpi + 1) * ncol <= 64) ++rpi;
+            int lr = (int)((float)lane / (float)ncol);
+            if (lr * ncol > lane) --lr; else if ((lr + 1) * ncol <= lane) ++lr;
+            const int lc = lane - lr * ncol;
+            const bool lact = lr < rpi;
+            const int tx8 = (c80 + lc) << 3;
+            u32 colmask = 0;
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) if (tx8 + bb >= cx0 && tx8 + bb < cx1) colmask |= 1u << bb;
             for (int pass = 0; pass < 2; ++pass) {
                 const int t = pass == 0 ? g.iniTh : g.minTh;
                 if (pass == 1 && g.minTh >= g.iniTh) break;               // a higher retry threshold cannot add corners
                 const u32 tt = (u32)t * 0x00010001u;
-                // ---- quick reject + compaction
+                // ---- quick reject + compaction: 8 px per lane, lane -> fixed 8-px column (no per-iteration index math)
                 int n1 = 0;
-                for (int gi0 = 0; gi0 < total; gi0 += 64) {
-                    const int gi = gi0 + lane;
+#ifdef F3_ABL_NOQUICK
+                for (int r0 = 0; r0 < 0; r0 += rpi) {
+#else
+                for (int r0 = 0; r0 < nrow; r0 += rpi) {
+#endif
+                    const int r = r0 + lr;
                     u32 m = 0;
-                    int ty = 0, tx = 0;
-                    if (gi < total) {
-                        int ry = (int)((float)gi * inv);
-                        int rem = gi - ry * ng;
-                        if (rem < 0) { --ry; rem += ng; } else if (rem >= ng) { ++ry; rem -= ng; }
-                        ty = vy0 + ry; tx = (gx0 + rem) << 2;
-                        const u32* rowc = (const u32*)(img + ty * Pb);
-                        const u32 B = rowc[tx >> 2], A = rowc[(tx >> 2) - 1], Cw = rowc[(tx >> 2) + 1];
-                        const u32 U = *(const u32*)(img + (ty - 3) * Pb + tx), D = *(const u32*)(img + (ty + 3) * Pb + tx);
-                        const u32 Lw = __builtin_amdgcn_alignbyte(B, A, 1);
-                        const u32 Rw = __builtin_amdgcn_alignbyte(Cw, B, 3);
+                    const int ty = vy0 + r;
+                    if (lact && r < nrow) {
+                        const u8* rowc = img + ty * Pb + tx8;
+                        const uint2 Bq = *(const uint2*)rowc;
+                        const u32 A = *(const u32*)(rowc - 4), Cw = *(const u32*)(rowc + 8);
+                        const uint2 Uq = *(const uint2*)(rowc - 3 * Pb), Dq = *(const uint2*)(rowc + 3 * Pb);
+                        const u32 Bv[2] = {Bq.x, Bq.y}, Uv[2] = {Uq.x, Uq.y}, Dv[2] = {Dq.x, Dq.y};
+                        const u32 Lv[2] = {__builtin_amdgcn_alignbyte(Bq.x, A, 1), __builtin_amdgcn_alignbyte(Bq.y, Bq.x, 1)};
+                        const u32 Rv[2] = {__builtin_amdgcn_alignbyte(Bq.y, Bq.x, 3), __builtin_amdgcn_alignbyte(Cw, Bq.y, 3)};
 #pragma unroll
-                        for (int hlf = 0; hlf < 2; ++hlf) {
-                            const u32 sel = hlf ? 0x0c030c02u : 0x0c010c00u;
-                            const us2 v = as_us2(__builtin_amdgcn_perm(0, B, sel)), up = as_us2(__builtin_amdgcn_perm(0, U, sel)),
-                                      dn = as_us2(__builtin_amdgcn_perm(0, D, sel)), lf = as_us2(__builtin_amdgcn_perm(0, Lw, sel)),
-                                      rt = as_us2(__builtin_amdgcn_perm(0, Rw, sel));
-                            const us2 t2 = as_us2(tt);
-                            const us2 X = pkmax(pkmin(up, dn), pkmin(lf, rt));
-                            const us2 Y = pkmin(pkmax(up, dn), pkmax(lf, rt));
-                            const u32 rr = as_u32((X - (v - t2)) | ((v + t2) - Y));
-                            m |= (((rr >> 15) & 1u) | ((rr >> 30) & 2u)) << (2 * hlf);
-                        }
-                        u32 vm = 0xFu;
-                        if (tx < cx0) vm &= 0xFu << (cx0 - tx);
-                        if (tx + 4 > cx1) vm &= 0xFu >> (tx + 4 - cx1);
-                        m &= vm;
-                    }
+                        for (int w4 = 0; w4 < 2; ++w4)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const bool f = (m >> b) & 1u;
-                        const unsigned long long bal = __ballot(f);
-                        if (f) q[n1 + __popcll(bal & lt)] = (u16)((ty << 9) | (tx + b));
-                        n1 += __popcll(bal);
+                            for (int hlf = 0; hlf < 2; ++hlf) {
+                                const u32 sel = hlf ? 0x0c030c02u : 0x0c010c00u;
+                                const us2 v = as_us2(__builtin_amdgcn_perm(0, Bv[w4], sel)), up = as_us2(__builtin_amdgcn_perm(0, Uv[w4], sel)),
+                                          dn = as_us2(__builtin_amdgcn_perm(0, Dv[w4], sel)), lf = as_us2(__builtin_amdgcn_perm(0, Lv[w4], sel)),
+                                          rt = as_us2(__builtin_amdgcn_perm(0, Rv[w4], sel));
+                                const us2 t2 = as_us2(tt);
+                                const us2 X = pkmax(pkmin(up, dn), pkmin(lf, rt));
+                                const us2 Y = pkmin(pkmax(up, dn), pkmax(lf, rt));
+                                const u32 rr = as_u32((X - (v - t2)) | ((v + t2) - Y));
+                                m |= (((rr >> 15) & 1u) | ((rr >> 30) & 2u)) << (4 * w4 + 2 * hlf);
+                            }
+                        m &= colmask;
                     }
+                    // wave prefix of popcount(m) (0..8) from 4 ballots, then each lane appends its own survivors
+                    const int c = __popc(m);
+                    int pre = 0, tot = 0;
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) {
+                        const unsigned long long bal = __ballot((c >> bb) & 1);
+                        pre += __popcll(bal & lt) << bb;
+                        tot += __popcll(bal) << bb;
+                    }
+                    int pos = n1 + pre;
+                    u32 mm = m;
+                    while (mm) {
+                        const int bpx = __builtin_ctz(mm);
+                        q[pos++] = (u16)((ty << 9) | (tx8 + bpx));
+                        mm &= mm - 1;
+                    }
+                    n1 += tot;
                 }
+#ifdef F3_ABL_NOSCORE
+                n1 = 0;
+#endif
                 // ---- exact score; keep pixels with S >= t (in place)
                 int n2 = 0;
                 for (int e0 = 0; e0 < n1; e0 += 64) {
