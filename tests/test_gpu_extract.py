@@ -107,3 +107,26 @@ def test_cpp_facade_runs(pkg, tmp_path):
     out = subprocess.run([exe, "need-gpu"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "keypoints" in out.stdout
+
+
+def test_device_resident_inputs_aligned_and_misaligned(pkg, oracle, synth):
+    """orbx_extract_batch_async with device pointers: 16-byte aligned inputs are read in place, anything else
+    (odd stride / odd base) is staged device-to-device; both must equal the host-image path bit for bit."""
+    import ctypes as C
+    for (w, h, stride, shift) in [(752, 480, 768, 0), (421, 307, 421, 0), (421, 307, 432, 4), (752, 480, 752, 16)]:
+        imgs = [synth.gen_image(w, h, 60 + i) for i in range(3)]
+        ex = pkg.ORBextractor(800, max_size=(w, h), max_batch=3)
+        want = ex.extract_batch(imgs)
+        dev = pkg.DeviceBuffer(3 * stride * h + 64)
+        ptrs = []
+        for i, im in enumerate(imgs):
+            pad = np.zeros((h, stride), np.uint8); pad[:, :w] = im
+            dev.upload(pad, offset=shift + i * stride * h)
+            ptrs.append(dev.ptr + shift + i * stride * h)
+        arr = (C.c_void_p * 3)(*ptrs)
+        ex.enqueue_device(arr, w, h, stride)
+        ex.sync()
+        for i in range(3):
+            mono, kps, desc = ex.fetch(i)
+            assert mono == want[i][0] and kps.tobytes() == want[i][1].tobytes() and np.array_equal(desc, want[i][2])
+        ex.close()
