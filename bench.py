@@ -50,10 +50,17 @@ def main():
     import torch.distributed as dist   # HIP library so both share one libamdhip64 runtime
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    local_rank = local_rank % max(ndev, 1)             # rehearsals may put several ranks on one GPU (gloo only)
     torch.cuda.set_device(local_rank)
+    backend = os.environ.get("ORB_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; "gloo" only for single-GPU rehearsals
+    cdev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pkg = importlib.import_module("orb-slam3_amd")
     synth = importlib.import_module("orb-slam3_amd.synth")
@@ -146,11 +153,11 @@ def main():
         L.orbx_memcpy_d2h(part.ctypes.data_as(C.c_void_p), res[h]["counts"], 4 * sizes[h])
         n_host[offs[h]:offs[h + 1]] = part
     dmod = importlib.import_module("orb-slam3_amd.dist")
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     # RCCL: the path's only exchange -- per-frame keypoint counts of every rank
-    gathered = dmod.gather_counts(n_host, device="cuda")
+    gathered = dmod.gather_counts(n_host, device=cdev)
     total_kp = torch.stack([g.sum() for g in gathered]).sum()
     dt = float(tmax.item())
 
