@@ -108,6 +108,19 @@ int orbm_search_by_projection_kf(orbm_t*, const orbm_frame_t* cur, const uint8_t
                                  int nq, const uint8_t* valid, const float* u, const float* v, const int32_t* level,
                                  const float* angle, const uint8_t* qdesc, float th, int orb_dist, int check_ori, int32_t* match);
 
+/* M6  ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th, ratioHamming) (ORBmatcher.cc:549-679; the
+ * +vpPointsKFs overload :681-797 matches identically).  valid[i] folds the caller-side Sim3 projection gates;
+ * matched_in[idx] = vpMatched[idx] != NULL; match[idx] = iMP or -1.  `kf` is the KeyFrame's view (KeyFrame.h:243-250,319). */
+int orbm_search_by_projection_sim3(orbm_t*, const orbm_frame_t* kf, const uint8_t* matched_in, const float* scale_factors,
+                                   int nq, const uint8_t* valid, const float* u, const float* v, const int32_t* level,
+                                   const uint8_t* qdesc, int th, float ratio_hamming, int32_t* match);
+
+/* M13 search core of ORBmatcher::Fuse (ORBmatcher.cc:1823-2049: chi2_gate = 1; Sim3 variant :2051-2199: chi2_gate = 0).
+ * best_idx[i] = KeyFrame feature MapPoint i fuses into, or -1; AddObservation / Replace stay with the caller. */
+int orbm_fuse(orbm_t*, const orbm_frame_t* kf, const float* scale_factors, const float* inv_sigma2,
+              int nq, const uint8_t* valid, const float* u, const float* v, const float* ur, const int32_t* level,
+              const uint8_t* qdesc, float th, int chi2_gate, int32_t* best_idx);
+
 /* M9  ORBmatcher::SearchForInitialization (ORBmatcher.cc:799-943); prev_matched_xy is updated in place */
 int orbm_search_for_initialization(orbm_t*, const orbm_frame_t* f1, const orbm_frame_t* f2, float* prev_matched_xy,
                                    int window, float nnratio, int check_ori, int32_t* matches12);

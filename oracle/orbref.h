@@ -138,6 +138,17 @@ int orbref_search_for_triangulation_legacy(int n1, const orbref_kp_t* kps1, cons
                                     int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2,
                                     const float* F12, float epx, float epy, const float* scale_factors2, const float* level_sigma2_2,
                                     int only_stereo, int coarse, int check_ori, int32_t* matches12);
+/* ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th, ratioHamming) (ORBmatcher.cc:549-679; the
+ * +vpPointsKFs overload :681-797 matches identically).  valid[i] folds the caller-side gates (bad / already found /
+ * depth / IsInImage / distance / normal); matched_in[idx] = vpMatched[idx] != NULL; match[idx] = iMP or -1. */
+int orbref_search_by_projection_sim3(const orbref_frame_t* kf, const uint8_t* matched_in, const float* scale_factors,
+                                     int nq, const uint8_t* valid, const float* u, const float* v, const int32_t* level,
+                                     const uint8_t* qdesc, int th, float ratio_hamming, int32_t* match);
+/* search core of ORBmatcher::Fuse (ORBmatcher.cc:1823-2049 with chi2_gate=1, Sim3 variant :2051-2199 with 0):
+ * best_idx[i] = KeyFrame feature the MapPoint i fuses into, or -1.  The map mutation stays with the caller. */
+int orbref_fuse(const orbref_frame_t* kf, const float* scale_factors, const float* inv_sigma2,
+                int nq, const uint8_t* valid, const float* u, const float* v, const float* ur, const int32_t* level,
+                const uint8_t* qdesc, float th, int chi2_gate, int32_t* best_idx);
 /* Frame::ComputeStereoMatches (Frame.cc:1027-1276).  Pyramids are those of the two extractors' last call. */
 int orbref_stereo_matches(const orbref_t* left, const orbref_t* right,
                           int nl, const orbref_kp_t* kl, const uint8_t* dl, int nr, const orbref_kp_t* kr, const uint8_t* dr,

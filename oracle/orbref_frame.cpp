@@ -494,6 +494,69 @@ int orbref_search_for_triangulation_legacy(int n1, const orbref_kp_t* kps1, cons
     return nmatches;
 }
 
+
+int orbref_search_by_projection_sim3(const orbref_frame_t* kf, const uint8_t* matched_in, const float* sf,
+                                     int nq, const uint8_t* valid, const float* u, const float* v, const int32_t* level,
+                                     const uint8_t* qdesc, int th, float ratioHamming, int32_t* match) {
+    int nmatches = 0;
+    std::vector<uint8_t> matched(matched_in, matched_in + kf->n);
+    for (int i = 0; i < kf->n; ++i) match[i] = -1;
+    std::vector<int> vIndices;
+    for (int iMP = 0; iMP < nq; ++iMP) {
+        if (!valid[iMP]) continue;
+        const int nPredictedLevel = level[iMP];
+        const float radius = th * sf[nPredictedLevel];
+        features_in_area(kf, u[iMP], v[iMP], radius, -1, -1, vIndices);       // KeyFrame::GetFeaturesInArea: no level filter
+        if (vIndices.empty()) continue;
+        int bestDist = 256, bestIdx = -1;
+        for (int idx : vIndices) {
+            if (matched[idx]) continue;
+            const int kpLevel = kf->kps[idx].octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const int dist = orbref_hamming(qdesc + 32 * (size_t)iMP, kf->desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW * ratioHamming) { match[bestIdx] = iMP; matched[bestIdx] = 1; nmatches++; }
+    }
+    return nmatches;
+}
+
+int orbref_fuse(const orbref_frame_t* kf, const float* sf, const float* inv_sigma2,
+                int nq, const uint8_t* valid, const float* u, const float* v, const float* ur, const int32_t* level,
+                const uint8_t* qdesc, float th, int chi2_gate, int32_t* best_idx) {
+    int nFused = 0;
+    std::vector<int> vIndices;
+    for (int i = 0; i < nq; ++i) {
+        best_idx[i] = -1;
+        if (!valid[i]) continue;
+        const int nPredictedLevel = level[i];
+        const float radius = th * sf[nPredictedLevel];
+        features_in_area(kf, u[i], v[i], radius, -1, -1, vIndices);
+        if (vIndices.empty()) continue;
+        int bestDist = chi2_gate ? 256 : INT_MAX, bestIdx = -1;
+        for (int idx : vIndices) {
+            const orbref_kp_t& kp = kf->kps[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (chi2_gate) {
+                if (kf->uright && kf->uright[idx] >= 0) {
+                    const float ex = u[i] - kp.x, ey = v[i] - kp.y, er = ur[i] - kf->uright[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_sigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float ex = u[i] - kp.x, ey = v[i] - kp.y;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_sigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            const int dist = orbref_hamming(qdesc + 32 * (size_t)i, kf->desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) { best_idx[i] = bestIdx; nFused++; }
+    }
+    return nFused;
+}
+
 int orbref_stereo_matches(const orbref_t* left, const orbref_t* right,
                           int N, const orbref_kp_t* kl, const uint8_t* dl, int Nr, const orbref_kp_t* kr, const uint8_t* dr,
                           float mb, float mbf, float* mvuRight, float* mvDepth) {

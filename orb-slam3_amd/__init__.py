@@ -363,6 +363,8 @@ def _bind_search(L, prefix):
     g("search_by_bow").argtypes = h + [ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, cf, ci, vp]
     g("search_for_triangulation_legacy").argtypes = g("search_for_triangulation").argtypes
     g("search_by_projection_kf").argtypes = h + [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp]
+    g("search_by_projection_sim3").argtypes = h + [vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, cf, vp]
+    g("fuse").argtypes = h + [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, vp]
     g("search_by_bow_kf").argtypes = h + [ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, cf, ci, vp]
 
 
@@ -452,6 +454,24 @@ class _SearchMixin:
                        float(th), int(orb_dist), int(check_ori), _p(match))
         return n, match
 
+    def SearchByProjectionSim3(self, kf, matched_in, scale_factors, valid, u, v, level, qdesc, th, ratio_hamming):
+        match = np.full(kf.n, -1, np.int32)
+        cs = kf.cstruct()
+        arr = [np.ascontiguousarray(a, t) for a, t in ((matched_in, np.uint8), (scale_factors, np.float32), (valid, np.uint8),
+               (u, np.float32), (v, np.float32), (level, np.int32), (qdesc, np.uint8))]
+        n = self._call("search_by_projection_sim3", C.byref(cs), _p(arr[0]), _p(arr[1]), len(arr[2]), *[_p(a) for a in arr[2:]],
+                       int(th), float(ratio_hamming), _p(match))
+        return n, match
+
+    def Fuse(self, kf, scale_factors, inv_sigma2, valid, u, v, ur, level, qdesc, th, chi2_gate=True):
+        best = np.full(len(valid), -1, np.int32)
+        cs = kf.cstruct()
+        arr = [np.ascontiguousarray(a, t) for a, t in ((scale_factors, np.float32), (inv_sigma2, np.float32), (valid, np.uint8),
+               (u, np.float32), (v, np.float32), (ur, np.float32), (level, np.int32), (qdesc, np.uint8))]
+        n = self._call("fuse", C.byref(cs), _p(arr[0]), _p(arr[1]), len(arr[2]), *[_p(a) for a in arr[2:]],
+                       float(th), int(chi2_gate), _p(best))
+        return n, best
+
     def SearchByBoWKF(self, k1, d1, good1, fv1, k2, d2, good2, fv2, nnratio, check_ori=True):
         m12 = np.full(len(k1), -1, np.int32)
         k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)
@@ -497,7 +517,7 @@ def _install_search():
     L.orbm_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     for name in ("grid_build", "SearchByProjectionFrame", "SearchByProjectionPoints", "SearchForInitialization",
-                 "SearchForTriangulation", "SearchByBoW", "SearchByProjectionKF", "SearchByBoWKF", "_call"):
+                 "SearchForTriangulation", "SearchByBoW", "SearchByProjectionKF", "SearchByBoWKF", "SearchByProjectionSim3", "Fuse", "_call"):
         setattr(ORBmatcher, name, getattr(_SearchMixin, name))
     ORBmatcher._prefix = "orbm_"
 
@@ -528,7 +548,8 @@ def _install_search():
 
 EXPORTS += ["orbm_grid_build", "orbm_window_candidates", "orbm_search_by_projection_frame", "orbm_search_by_projection_points",
             "orbm_search_for_initialization", "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_stereo_matches",
-            "orbm_search_by_projection_kf", "orbm_search_by_bow_kf", "orbm_search_for_triangulation_legacy"]
+            "orbm_search_by_projection_kf", "orbm_search_by_bow_kf", "orbm_search_for_triangulation_legacy",
+            "orbm_search_by_projection_sim3", "orbm_fuse"]
 _orig_lib = lib
 _search_ready = False
 

@@ -572,6 +572,80 @@ int orbm_search_by_projection_kf(orbm_t* m, const orbm_frame_t* cur, const uint8
     return nmatches;
 }
 
+int orbm_search_by_projection_sim3(orbm_t* m, const orbm_frame_t* kf, const uint8_t* matched_in, const float* sf,
+                                   int nq, const uint8_t* valid, const float* u, const float* v, const int32_t* level,
+                                   const uint8_t* qdesc, int th, float ratioHamming, int32_t* match) {
+    if (!m || !kf || nq < 0) return ORBM_E_INVALID;
+    std::vector<float> qr(nq);
+    std::vector<int> minl(nq), maxl(nq);
+    for (int i = 0; i < nq; ++i) {
+        if (!valid[i]) { qr[i] = -1.f; minl[i] = 0; maxl[i] = -1; continue; }
+        qr[i] = th * sf[level[i]]; minl[i] = level[i] - 1; maxl[i] = level[i];          // :600-601, :625-627
+    }
+    const int cap = std::max(1, std::min(kf->n, 2048));
+    std::vector<int> cnt, idx, dist;
+    orbm_frame_t f = *kf; f.uright = nullptr;
+    int rc = window_pass(m, &f, nq, u, v, qr.data(), minl.data(), maxl.data(), nullptr, nullptr, qdesc, cap, cnt, idx, dist);
+    if (rc) return rc;
+    int nmatches = 0;
+    std::vector<uint8_t> matched(matched_in, matched_in + kf->n);
+    for (int i = 0; i < kf->n; ++i) match[i] = -1;
+    for (int i = 0; i < nq; ++i) {
+        if (!valid[i] || cnt[i] == 0) continue;
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < cnt[i]; ++c) {
+            const int k = idx[(size_t)i * cap + c];
+            if (matched[k]) continue;                                        // :621-622
+            const int d = dist[(size_t)i * cap + c];
+            if (d < bestDist) { bestDist = d; bestIdx = k; }
+        }
+        if (bestDist <= ORBM_TH_LOW * ratioHamming) { match[bestIdx] = i; matched[bestIdx] = 1; nmatches++; }
+    }
+    return nmatches;
+}
+
+int orbm_fuse(orbm_t* m, const orbm_frame_t* kf, const float* sf, const float* inv_sigma2,
+              int nq, const uint8_t* valid, const float* u, const float* v, const float* ur, const int32_t* level,
+              const uint8_t* qdesc, float th, int chi2_gate, int32_t* best_idx) {
+    if (!m || !kf || nq < 0) return ORBM_E_INVALID;
+    std::vector<float> qr(nq);
+    std::vector<int> minl(nq), maxl(nq);
+    for (int i = 0; i < nq; ++i) {
+        if (!valid[i]) { qr[i] = -1.f; minl[i] = 0; maxl[i] = -1; continue; }
+        qr[i] = th * sf[level[i]]; minl[i] = level[i] - 1; maxl[i] = level[i];
+    }
+    const int cap = std::max(1, std::min(kf->n, 2048));
+    std::vector<int> cnt, idx, dist;
+    orbm_frame_t f = *kf; f.uright = nullptr;                               // the chi2 gate below is not a window gate
+    int rc = window_pass(m, &f, nq, u, v, qr.data(), minl.data(), maxl.data(), nullptr, nullptr, qdesc, cap, cnt, idx, dist);
+    if (rc) return rc;
+    int nFused = 0;
+    for (int i = 0; i < nq; ++i) {
+        best_idx[i] = -1;
+        if (!valid[i] || cnt[i] == 0) continue;
+        int bestDist = chi2_gate ? 256 : INT_MAX, bestIdx = -1;
+        for (int c = 0; c < cnt[i]; ++c) {
+            const int k = idx[(size_t)i * cap + c];
+            if (chi2_gate) {                                                 // :1925-1949
+                const orbm_kp_t& kp = kf->kps[k];
+                if (kf->uright && kf->uright[k] >= 0) {
+                    const float ex = u[i] - kp.x, ey = v[i] - kp.y, er = ur[i] - kf->uright[k];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_sigma2[kp.octave] > 7.8) continue;
+                } else {
+                    const float ex = u[i] - kp.x, ey = v[i] - kp.y;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_sigma2[kp.octave] > 5.99) continue;
+                }
+            }
+            const int d = dist[(size_t)i * cap + c];
+            if (d < bestDist) { bestDist = d; bestIdx = k; }
+        }
+        if (bestDist <= ORBM_TH_LOW) { best_idx[i] = bestIdx; nFused++; }
+    }
+    return nFused;
+}
+
 int orbm_search_by_bow_kf(orbm_t* m, int n1, const orbm_kp_t* kps1, const uint8_t* desc1, const uint8_t* good1,
                           int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
                           int n2, const orbm_kp_t* kps2, const uint8_t* desc2, const uint8_t* good2,

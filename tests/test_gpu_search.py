@@ -183,6 +183,37 @@ def test_search_for_triangulation_legacy(pkg, scene, bits, coarse, ori):
         assert len(np.unique(taken)) == len(taken)          # vbMatched2 keeps the matching one-to-one
 
 
+@pytest.mark.parametrize("th,ratio", [(8, 1.5), (4, 1.0), (15, 2.0)])
+def test_search_by_projection_sim3(pkg, scene, th, ratio):
+    # loop closing: LoopClosing.cc uses th = 8, ratioHamming = 1.5 for the Sim3 guided search
+    rng = np.random.default_rng(th * 3)
+    kr = scene["kr"]
+    views = [pkg.FrameView(kr, scene["dr"], 752, 480, backend=b) for b in (scene["m"], scene["OM"])]
+    n, u, v = _queries(scene, rng)
+    lvl = np.clip(scene["kl"]["octave"] + rng.integers(0, 2, n), 0, 7)
+    args = dict(matched_in=rng.random(len(kr)) < 0.15, scale_factors=scene["sf"], valid=rng.random(n) < 0.7, u=u, v=v, level=lvl,
+                qdesc=scene["dl"], th=th, ratio_hamming=ratio)
+    n_gpu, m_gpu = scene["m"].SearchByProjectionSim3(views[0], **args)
+    n_ref, m_ref = scene["OM"].SearchByProjectionSim3(views[1], **args)
+    assert n_gpu == n_ref and np.array_equal(m_gpu, m_ref) and n_ref > 10
+
+
+@pytest.mark.parametrize("th,chi2,stereo", [(3.0, True, True), (3.0, True, False), (4.0, False, False)])
+def test_fuse_search_core(pkg, scene, th, chi2, stereo):
+    rng = np.random.default_rng(int(th) + chi2 + 2 * stereo)
+    kr = scene["kr"]
+    urk = np.where(rng.random(len(kr)) < 0.6, kr["x"] - rng.uniform(2, 40, len(kr)), -1).astype(np.float32) if stereo else None
+    views = [pkg.FrameView(kr, scene["dr"], 752, 480, uright=urk, backend=b) for b in (scene["m"], scene["OM"])]
+    n, u, v = _queries(scene, rng, jitter=1.0)
+    lvl = np.clip(scene["kl"]["octave"] + rng.integers(0, 2, n), 0, 7)
+    inv_sigma2 = (1.0 / scene["sigma2"]).astype(np.float32)
+    args = dict(scale_factors=scene["sf"], inv_sigma2=inv_sigma2, valid=rng.random(n) < 0.8, u=u, v=v,
+                ur=(u - rng.uniform(2, 40, n)).astype(np.float32), level=lvl, qdesc=scene["dl"], th=th, chi2_gate=chi2)
+    n_gpu, b_gpu = scene["m"].Fuse(views[0], **args)
+    n_ref, b_ref = scene["OM"].Fuse(views[1], **args)
+    assert n_gpu == n_ref and np.array_equal(b_gpu, b_ref)
+
+
 def test_compute_stereo_matches(pkg, scene):
     # EuRoC stereo: bf = 47.906, fx = 435.2 -> mb = bf/fx (Examples/Stereo/EuRoC.yaml:9,28)
     mbf = 47.90639384423901; mb = mbf / 435.2046959714599
