@@ -121,6 +121,14 @@ int orbm_fuse(orbm_t*, const orbm_frame_t* kf, const float* scale_factors, const
               int nq, const uint8_t* valid, const float* u, const float* v, const float* ur, const int32_t* level,
               const uint8_t* qdesc, float th, int chi2_gate, int32_t* best_idx);
 
+/* M13 ORBmatcher::SearchBySim3 (ORBmatcher.cc:2201-2467): two independent guided searches (KeyFrame 1's MapPoints in
+ * KeyFrame 2 and vice versa; projections + gates done by the caller) and the mutual-consistency check.
+ * matches12[i1] = idx2 or -1; returns nFound. */
+int orbm_search_by_sim3(orbm_t*, const orbm_frame_t* kf1, const orbm_frame_t* kf2, const float* sf1, const float* sf2,
+                        const uint8_t* valid1, const float* u1, const float* v1, const int32_t* level1, const uint8_t* qdesc1,
+                        const uint8_t* valid2, const float* u2, const float* v2, const int32_t* level2, const uint8_t* qdesc2,
+                        float th, int32_t* matches12);
+
 /* M9  ORBmatcher::SearchForInitialization (ORBmatcher.cc:799-943); prev_matched_xy is updated in place */
 int orbm_search_for_initialization(orbm_t*, const orbm_frame_t* f1, const orbm_frame_t* f2, float* prev_matched_xy,
                                    int window, float nnratio, int check_ori, int32_t* matches12);

@@ -149,6 +149,13 @@ int orbref_search_by_projection_sim3(const orbref_frame_t* kf, const uint8_t* ma
 int orbref_fuse(const orbref_frame_t* kf, const float* scale_factors, const float* inv_sigma2,
                 int nq, const uint8_t* valid, const float* u, const float* v, const float* ur, const int32_t* level,
                 const uint8_t* qdesc, float th, int chi2_gate, int32_t* best_idx);
+/* ORBmatcher::SearchBySim3 (ORBmatcher.cc:2201-2467): valid1/u1/v1/level1/qdesc1 describe KeyFrame 1's MapPoints
+ * projected into KeyFrame 2 (caller-side Sim3 + gates), valid2/... the reverse; matches12[i1] = idx2 for mutually
+ * consistent pairs, else -1.  Returns nFound. */
+int orbref_search_by_sim3(const orbref_frame_t* kf1, const orbref_frame_t* kf2, const float* sf1, const float* sf2,
+                          const uint8_t* valid1, const float* u1, const float* v1, const int32_t* level1, const uint8_t* qdesc1,
+                          const uint8_t* valid2, const float* u2, const float* v2, const int32_t* level2, const uint8_t* qdesc2,
+                          float th, int32_t* matches12);
 /* Frame::ComputeStereoMatches (Frame.cc:1027-1276).  Pyramids are those of the two extractors' last call. */
 int orbref_stereo_matches(const orbref_t* left, const orbref_t* right,
                           int nl, const orbref_kp_t* kl, const uint8_t* dl, int nr, const orbref_kp_t* kr, const uint8_t* dr,

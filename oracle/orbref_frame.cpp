@@ -557,6 +557,44 @@ int orbref_fuse(const orbref_frame_t* kf, const float* sf, const float* inv_sigm
     return nFused;
 }
 
+
+static void sim3_one_way(const orbref_frame_t* src, const orbref_frame_t* dst, const float* sf_dst, const uint8_t* valid,
+                         const float* u, const float* v, const int32_t* level, const uint8_t* qdesc, float th, std::vector<int>& vnMatch) {
+    vnMatch.assign(src->n, -1);
+    std::vector<int> vIndices;
+    for (int i = 0; i < src->n; ++i) {
+        if (!valid[i]) continue;
+        const int nPredictedLevel = level[i];
+        const float radius = th * sf_dst[nPredictedLevel];
+        features_in_area(dst, u[i], v[i], radius, -1, -1, vIndices);
+        if (vIndices.empty()) continue;
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (int idx : vIndices) {
+            const int oct = dst->kps[idx].octave;
+            if (oct < nPredictedLevel - 1 || oct > nPredictedLevel) continue;
+            const int dist = orbref_hamming(qdesc + 32 * (size_t)i, dst->desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_HIGH) vnMatch[i] = bestIdx;
+    }
+}
+
+int orbref_search_by_sim3(const orbref_frame_t* kf1, const orbref_frame_t* kf2, const float* sf1, const float* sf2,
+                          const uint8_t* valid1, const float* u1, const float* v1, const int32_t* level1, const uint8_t* qdesc1,
+                          const uint8_t* valid2, const float* u2, const float* v2, const int32_t* level2, const uint8_t* qdesc2,
+                          float th, int32_t* matches12) {
+    std::vector<int> vnMatch1, vnMatch2;
+    sim3_one_way(kf1, kf2, sf2, valid1, u1, v1, level1, qdesc1, th, vnMatch1);   // :2247-2318
+    sim3_one_way(kf2, kf1, sf1, valid2, u2, v2, level2, qdesc2, th, vnMatch2);   // :2321-2392
+    int nFound = 0;
+    for (int i1 = 0; i1 < kf1->n; ++i1) {
+        matches12[i1] = -1;
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0 && vnMatch2[idx2] == i1) { matches12[i1] = idx2; nFound++; }
+    }
+    return nFound;
+}
+
 int orbref_stereo_matches(const orbref_t* left, const orbref_t* right,
                           int N, const orbref_kp_t* kl, const uint8_t* dl, int Nr, const orbref_kp_t* kr, const uint8_t* dr,
                           float mb, float mbf, float* mvuRight, float* mvDepth) {

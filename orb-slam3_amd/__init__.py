@@ -364,6 +364,7 @@ def _bind_search(L, prefix):
     g("search_for_triangulation_legacy").argtypes = g("search_for_triangulation").argtypes
     g("search_by_projection_kf").argtypes = h + [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp]
     g("search_by_projection_sim3").argtypes = h + [vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, cf, vp]
+    g("search_by_sim3").argtypes = h + [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, vp]
     g("fuse").argtypes = h + [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, vp]
     g("search_by_bow_kf").argtypes = h + [ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, cf, ci, vp]
 
@@ -463,6 +464,18 @@ class _SearchMixin:
                        int(th), float(ratio_hamming), _p(match))
         return n, match
 
+    def SearchBySim3(self, kf1, kf2, sf1, sf2, q1, q2, th):
+        """q1 / q2: dicts with valid, u, v, level, qdesc for the KF1->KF2 and KF2->KF1 projections."""
+        m12 = np.full(kf1.n, -1, np.int32)
+        c1, c2 = kf1.cstruct(), kf2.cstruct()
+        s1 = np.ascontiguousarray(sf1, np.float32); s2 = np.ascontiguousarray(sf2, np.float32)
+        def pack(q):
+            return [np.ascontiguousarray(q["valid"], np.uint8), np.ascontiguousarray(q["u"], np.float32), np.ascontiguousarray(q["v"], np.float32),
+                    np.ascontiguousarray(q["level"], np.int32), np.ascontiguousarray(q["qdesc"], np.uint8)]
+        a1, a2 = pack(q1), pack(q2)
+        n = self._call("search_by_sim3", C.byref(c1), C.byref(c2), _p(s1), _p(s2), *[_p(a) for a in a1], *[_p(a) for a in a2], float(th), _p(m12))
+        return n, m12
+
     def Fuse(self, kf, scale_factors, inv_sigma2, valid, u, v, ur, level, qdesc, th, chi2_gate=True):
         best = np.full(len(valid), -1, np.int32)
         cs = kf.cstruct()
@@ -517,7 +530,7 @@ def _install_search():
     L.orbm_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     for name in ("grid_build", "SearchByProjectionFrame", "SearchByProjectionPoints", "SearchForInitialization",
-                 "SearchForTriangulation", "SearchByBoW", "SearchByProjectionKF", "SearchByBoWKF", "SearchByProjectionSim3", "Fuse", "_call"):
+                 "SearchForTriangulation", "SearchByBoW", "SearchByProjectionKF", "SearchByBoWKF", "SearchByProjectionSim3", "Fuse", "SearchBySim3", "_call"):
         setattr(ORBmatcher, name, getattr(_SearchMixin, name))
     ORBmatcher._prefix = "orbm_"
 
@@ -549,7 +562,7 @@ def _install_search():
 EXPORTS += ["orbm_grid_build", "orbm_window_candidates", "orbm_search_by_projection_frame", "orbm_search_by_projection_points",
             "orbm_search_for_initialization", "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_stereo_matches",
             "orbm_search_by_projection_kf", "orbm_search_by_bow_kf", "orbm_search_for_triangulation_legacy",
-            "orbm_search_by_projection_sim3", "orbm_fuse"]
+            "orbm_search_by_projection_sim3", "orbm_fuse", "orbm_search_by_sim3"]
 _orig_lib = lib
 _search_ready = False
 

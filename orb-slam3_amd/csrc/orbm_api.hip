@@ -646,6 +646,52 @@ int orbm_fuse(orbm_t* m, const orbm_frame_t* kf, const float* sf, const float* i
     return nFused;
 }
 
+static int sim3_one_way(orbm* m, const orbm_frame_t* src, const orbm_frame_t* dst, const float* sf_dst, const uint8_t* valid,
+                        const float* u, const float* v, const int32_t* level, const uint8_t* qdesc, float th, std::vector<int>& vnMatch) {
+    const int nq = src->n;
+    vnMatch.assign(nq, -1);
+    std::vector<float> qr(nq);
+    std::vector<int> minl(nq), maxl(nq);
+    for (int i = 0; i < nq; ++i) {
+        if (!valid[i]) { qr[i] = -1.f; minl[i] = 0; maxl[i] = -1; continue; }
+        qr[i] = th * sf_dst[level[i]]; minl[i] = level[i] - 1; maxl[i] = level[i];
+    }
+    const int cap = std::max(1, std::min(dst->n, 2048));
+    std::vector<int> cnt, idx, dist;
+    orbm_frame_t f = *dst; f.uright = nullptr;
+    int rc = window_pass(m, &f, nq, u, v, qr.data(), minl.data(), maxl.data(), nullptr, nullptr, qdesc, cap, cnt, idx, dist);
+    if (rc) return rc;
+    for (int i = 0; i < nq; ++i) {
+        if (!valid[i]) continue;
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (int c = 0; c < cnt[i]; ++c) {
+            const int d = dist[(size_t)i * cap + c];
+            if (d < bestDist) { bestDist = d; bestIdx = idx[(size_t)i * cap + c]; }
+        }
+        if (bestDist <= ORBM_TH_HIGH) vnMatch[i] = bestIdx;
+    }
+    return ORBM_OK;
+}
+
+int orbm_search_by_sim3(orbm_t* m, const orbm_frame_t* kf1, const orbm_frame_t* kf2, const float* sf1, const float* sf2,
+                        const uint8_t* valid1, const float* u1, const float* v1, const int32_t* level1, const uint8_t* qdesc1,
+                        const uint8_t* valid2, const float* u2, const float* v2, const int32_t* level2, const uint8_t* qdesc2,
+                        float th, int32_t* matches12) {
+    if (!m || !kf1 || !kf2) return ORBM_E_INVALID;
+    std::vector<int> vnMatch1, vnMatch2;
+    int rc = sim3_one_way(m, kf1, kf2, sf2, valid1, u1, v1, level1, qdesc1, th, vnMatch1);
+    if (rc) return rc;
+    rc = sim3_one_way(m, kf2, kf1, sf1, valid2, u2, v2, level2, qdesc2, th, vnMatch2);
+    if (rc) return rc;
+    int nFound = 0;
+    for (int i1 = 0; i1 < kf1->n; ++i1) {
+        matches12[i1] = -1;
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0 && vnMatch2[idx2] == i1) { matches12[i1] = idx2; nFound++; }
+    }
+    return nFound;
+}
+
 int orbm_search_by_bow_kf(orbm_t* m, int n1, const orbm_kp_t* kps1, const uint8_t* desc1, const uint8_t* good1,
                           int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
                           int n2, const orbm_kp_t* kps2, const uint8_t* desc2, const uint8_t* good2,

@@ -214,6 +214,22 @@ def test_fuse_search_core(pkg, scene, th, chi2, stereo):
     assert n_gpu == n_ref and np.array_equal(b_gpu, b_ref)
 
 
+def test_search_by_sim3(pkg, scene):
+    rng = np.random.default_rng(77)
+    kl, kr, dl, dr = scene["kl"], scene["kr"], scene["dl"], scene["dr"]
+    # true correspondences of the synthetic pair are a pure x-shift (disparity): project each set onto the other roughly
+    q1 = dict(valid=rng.random(len(kl)) < 0.8, u=(kl["x"] - 20 + rng.normal(0, 4, len(kl))).astype(np.float32), v=kl["y"].copy(),
+              level=np.clip(kl["octave"] + rng.integers(0, 2, len(kl)), 0, 7), qdesc=dl)
+    q2 = dict(valid=rng.random(len(kr)) < 0.8, u=(kr["x"] + 20 + rng.normal(0, 4, len(kr))).astype(np.float32), v=kr["y"].copy(),
+              level=np.clip(kr["octave"] + rng.integers(0, 2, len(kr)), 0, 7), qdesc=dr)
+    out = []
+    for b in (scene["m"], scene["OM"]):
+        f1 = pkg.FrameView(kl, dl, 752, 480, backend=b); f2 = pkg.FrameView(kr, dr, 752, 480, backend=b)
+        out.append(b.SearchBySim3(f1, f2, scene["sf"], scene["sf"], q1, q2, 7.5))
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    assert out[0][0] > 20
+
+
 def test_compute_stereo_matches(pkg, scene):
     # EuRoC stereo: bf = 47.906, fx = 435.2 -> mb = bf/fx (Examples/Stereo/EuRoC.yaml:9,28)
     mbf = 47.90639384423901; mb = mbf / 435.2046959714599
