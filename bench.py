@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic frames generated per rank")
+    ap.add_argument("--match", choices=["window", "knn2"], default="knn2",
+                    help="match leg: 'window' = the mono SearchByProjection window search of every frame's keypoints in the previous "
+                         "frame (grid gather + Hamming, ORBmatcher.cc:2543-2612); 'knn2' = dense brute-force 2-NN (Frame.cc:1440-1480)")
     ap.add_argument("--handles", type=int, default=1, help="extractor handles kept in flight per GPU (the batch is split over them)")
     ap.add_argument("--cpu-sample", type=int, default=96, help="frames timed through the CPU oracle (0 = skip)")
     args = ap.parse_args()
@@ -92,6 +95,11 @@ def main():
     idx2 = [pkg.DeviceBuffer(max(1, sizes[h]) * cap * 2 * 4) for h in range(NH)]
     dist2 = [pkg.DeviceBuffer(max(1, sizes[h]) * cap * 2 * 4) for h in range(NH)]
     xidx = pkg.DeviceBuffer(NH * cap * 2 * 4); xdist = pkg.DeviceBuffer(NH * cap * 2 * 4)
+    gstart = [pkg.DeviceBuffer(max(1, sizes[h]) * 3073 * 4) for h in range(NH)]
+    gidx = [pkg.DeviceBuffer(max(1, sizes[h]) * cap * 4) for h in range(NH)]
+    sdist = [pkg.DeviceBuffer(max(1, sizes[h]) * cap * 4) for h in range(NH)]
+    sf_host = ex.GetScaleFactors()
+    inv_w = float(np.float32(64) / np.float32(W)); inv_h = float(np.float32(48) / np.float32(H))   # Frame.cc:401-402, identity undistortion
 
     def step():
         for h in range(NH):
@@ -104,6 +112,19 @@ def main():
             ms = L.orbm_stream(mts[h].h)
             L.orbx_stream_wait_results(exs[h].h, ms)
             r = res[h]
+            if args.match == "window":
+                # Frame grid (M14) for every frame, then each frame's keypoints search the previous frame inside the
+                # SearchByProjection window th=15 (mono, Tracking.cc:3203-3208); frames of other handles are skipped here
+                rc = L.orbm_grid_build_batch_async(mts[h].h, r["kps"], r["counts"], sizes[h], cap, 0.0, 0.0, inv_w, inv_h,
+                                                   gstart[h].ptr, gidx[h].ptr)
+                assert rc == 0, rc
+                if sizes[h] > 1:
+                    rc = L.orbm_track_window_batch_async(mts[h].h, r["kps"], r["desc"], r["counts"], cap, gstart[h].ptr, gidx[h].ptr,
+                                                         0.0, 0.0, inv_w, inv_h, 1, 0, sizes[h] - 1, 15.0,
+                                                         sf_host.ctypes.data_as(C.c_void_p), 8, 0.0, 0.0,
+                                                         idx2[h].ptr, dist2[h].ptr, sdist[h].ptr)
+                    assert rc == 0, rc
+                continue
             # dense 2-NN Hamming match of frame i (query) against frame i-1 (train) inside the half-batch ...
             if sizes[h] > 1:
                 rc = L.orbm_knn2_batch_async(mts[h].h, r["desc"] + cap * 32, cap, r["counts"] + 4, r["desc"], cap, r["counts"],
@@ -177,15 +198,16 @@ def main():
         except Exception:
             traffic = None
         stage = {k: float(np.mean([tm[k] for tm, _ in t_all])) for k in t_all[0][0]}
-        stage["knn2"] = mt.timing_ms()
+        stage["match_" + args.match] = mt.timing_ms()
         out = {
             "metric": "ORB extract+match frames/sec @752x480, 1000 feat",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "configs[1]: %dx%d grayscale, %d features, 8 levels, scale 1.2, FAST 20/7; "
-                                   "batch of %d frames/GPU/step resident in HBM; extract + dense 2-NN Hamming "
-                                   "match against the previous frame" % (W, H, args.nfeatures, B),
+                                   "batch of %d frames/GPU/step resident in HBM; extract + %s against the previous frame"
+                                   % (W, H, args.nfeatures, B, "Frame grid build and SearchByProjection window match (th=15) of every keypoint"
+                                      if args.match == "window" else "dense 2-NN Hamming match"),
                        "frames_per_step_per_gpu": B, "handles_in_flight": NH, "keypoints_last_batch": int(total_kp.item())},
             "roofline": {"bound": "hbm", "kernel": "pyramid+FAST pass (k_resize2 x7 on stream 2 + k_fast3 x2 on stream 1; wall span by HIP events)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -197,18 +219,25 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import orbref                                   # the checker, timed as the CPU baseline ("port")
             ref = orbref.Extractor(args.nfeatures, 1.2, 8, 20, 7)
+            OM = orbref._oracle_matcher_class()()
             ns = args.cpu_sample
             prev = None
             tc = time.perf_counter()
             for i in range(ns):
                 n, kps, desc, mono = ref(host_imgs[i % len(host_imgs)], (0, 1000))
                 if prev is not None:
-                    orbref.knn2(desc, prev)
-                prev = desc
+                    if args.match == "knn2":
+                        orbref.knn2(desc, prev[1])
+                    else:                                   # the oracle's SearchByProjection(Frame,Frame) in C over the same windows
+                        fv = pkg.FrameView(prev[0], prev[1], W, H, backend=OM)
+                        nq = len(kps)
+                        OM.SearchByProjectionFrame(fv, np.zeros(fv.n, np.uint8), ref.tables()["sf"], np.ones(nq, np.uint8), kps["x"], kps["y"],
+                                                   np.zeros(nq, np.float32), kps["octave"], kps["angle"], desc, np.zeros(nq, np.uint8), 15.0)
+                prev = (kps, desc)
             tcpu = time.perf_counter() - tc
             out["cpu_baseline"] = {"value": ns / tcpu, "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": "%d frames of the same synthetic stream through oracle/liborbref.so "
-                                             "(extract + 2-NN match vs previous frame), 1 thread" % ns,
+                                             "(extract + %s match vs previous frame), 1 thread" % (ns, args.match),
                                    "stage_ms_per_frame": {k: v / ns for k, v in ref.stage_ms().items()}}
         print(json.dumps(out))
     if world > 1:

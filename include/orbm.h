@@ -166,6 +166,21 @@ int orbm_search_for_triangulation_legacy(orbm_t*, int n1, const orbm_kp_t* kps1,
                                   const float* F12, float epx, float epy, const float* scale_factors2, const float* level_sigma2_2,
                                   int only_stereo, int coarse, int check_ori, int32_t* matches12);
 
+/* ---- batched, DEVICE-resident forms: frame-to-frame tracking chained behind orbx_extract_batch_async with no host round
+ * trip (kps/desc/counts are the extractor's result block, orbx_result_device; all pointers are device pointers).
+ * orbm_grid_build_batch_async: M14 for every frame of the block; grid_start [nframes][3073], grid_idx [nframes][cap].
+ * orbm_track_window_batch_async: for pair p the keypoints of frame q_first+p search frame t_first+p inside the mono
+ * SearchByProjection window (centre (x+dx, y+dy), radius th*scale[octave], levels octave-1..octave+1,
+ * ORBmatcher.cc:2543-2549): first-minimum best index/distance and runner-up distance per keypoint, [npairs][cap].
+ * This is the claim-free, data-parallel part; sequential claim replay (M4) needs the host entry point above. */
+int orbm_grid_build_batch_async(orbm_t*, const orbm_kp_t* kps, const int32_t* counts, int nframes, int cap,
+                                float min_x, float min_y, float inv_w, float inv_h, int32_t* grid_start, int32_t* grid_idx);
+int orbm_track_window_batch_async(orbm_t*, const orbm_kp_t* kps, const uint8_t* desc, const int32_t* counts, int cap,
+                                  const int32_t* grid_start, const int32_t* grid_idx,
+                                  float min_x, float min_y, float inv_w, float inv_h,
+                                  int q_first, int t_first, int npairs, float th, const float* scale_factors_host, int nlevels,
+                                  float dx, float dy, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);
+
 /* M15 Frame::ComputeStereoMatches (Frame.cc:1027-1276).  left/right are orbx_t* extractor handles (include/orbx.h)
  * on the same device whose LAST call produced the two keypoint sets: their device-resident pyramids supply the
  * 11x11 SAD windows (mvImagePyramid, include/ORBextractor.h:83).  frame_l/frame_r select the batch slot.

@@ -555,6 +555,11 @@ def _install_search():
                                             float(mb), float(mbf), _p(ur), _p(dp)), "stereo_matches")
         return n, ur[:len(kl)], dp[:len(kl)]
 
+    L.orbm_grid_build_batch_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                              C.c_float, C.c_void_p, C.c_void_p]
+    L.orbm_track_window_batch_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float,
+                                                C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     ORBmatcher.window_candidates = window_candidates
     ORBmatcher.ComputeStereoMatches = stereo_matches
 
@@ -562,7 +567,8 @@ def _install_search():
 EXPORTS += ["orbm_grid_build", "orbm_window_candidates", "orbm_search_by_projection_frame", "orbm_search_by_projection_points",
             "orbm_search_for_initialization", "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_stereo_matches",
             "orbm_search_by_projection_kf", "orbm_search_by_bow_kf", "orbm_search_for_triangulation_legacy",
-            "orbm_search_by_projection_sim3", "orbm_fuse", "orbm_search_by_sim3"]
+            "orbm_search_by_projection_sim3", "orbm_fuse", "orbm_search_by_sim3",
+            "orbm_grid_build_batch_async", "orbm_track_window_batch_async"]
 _orig_lib = lib
 _search_ready = False
 

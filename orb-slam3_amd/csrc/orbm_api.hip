@@ -26,8 +26,8 @@ static void set_merr(const char* fmt, ...) {
 struct orbm {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    bool timed = false;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    bool timed = false, gridFirst = false;
 };
 
 extern "C" {
@@ -44,7 +44,7 @@ int orbm_create(orbm_t** out, int device_id) {
     orbm* m = new orbm;
     m->device = device_id;
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->e0) != hipSuccess ||
-        hipEventCreate(&m->e1) != hipSuccess) { set_merr("stream/event creation failed"); orbm_destroy(m); return ORBM_E_HIP; }
+        hipEventCreate(&m->e1) != hipSuccess || hipEventCreate(&m->e2) != hipSuccess) { set_merr("stream/event creation failed"); orbm_destroy(m); return ORBM_E_HIP; }
     *out = m;
     return ORBM_OK;
 }
@@ -55,6 +55,7 @@ void orbm_destroy(orbm_t* m) {
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     if (m->e0) (void)hipEventDestroy(m->e0);
     if (m->e1) (void)hipEventDestroy(m->e1);
+    if (m->e2) (void)hipEventDestroy(m->e2);
     delete m;
 }
 
@@ -92,6 +93,7 @@ int orbm_knn2_batch_async(orbm_t* m, const uint8_t* q, int q_stride, const int32
     (void)max_nt;
     if (!m || !q || !t || !nq || !nt || !idx2 || !dist2 || npairs < 1 || q_stride < 1 || t_stride < 1) return ORBM_E_INVALID;
     MHIPCHK(hipSetDevice(m->device));
+    m->gridFirst = false;
     MHIPCHK(hipEventRecord(m->e0, m->stream));
     hipLaunchKernelGGL(k_knn2, dim3((q_stride + 63) / 64, npairs), dim3(256), 0, m->stream, q, q_stride, nq, t, t_stride, nt, idx2, dist2);
     MHIPCHK(hipEventRecord(m->e1, m->stream));
@@ -136,7 +138,7 @@ int orbm_last_timing(orbm_t* m, float* ms) {
     if (!m || !m->timed) return ORBM_E_INVALID;
     MHIPCHK(hipSetDevice(m->device));
     MHIPCHK(hipStreamSynchronize(m->stream));
-    MHIPCHK(hipEventElapsedTime(ms, m->e0, m->e1));
+    MHIPCHK(hipEventElapsedTime(ms, m->gridFirst ? m->e2 : m->e0, m->e1));
     return ORBM_OK;
 }
 
@@ -690,6 +692,40 @@ int orbm_search_by_sim3(orbm_t* m, const orbm_frame_t* kf1, const orbm_frame_t* 
         if (idx2 >= 0 && vnMatch2[idx2] == i1) { matches12[i1] = idx2; nFound++; }
     }
     return nFound;
+}
+
+int orbm_grid_build_batch_async(orbm_t* m, const orbm_kp_t* kps, const int32_t* counts, int nframes, int cap,
+                                float min_x, float min_y, float inv_w, float inv_h, int32_t* grid_start, int32_t* grid_idx) {
+    if (!m || !kps || !counts || !grid_start || !grid_idx || nframes < 1 || cap < 1 || cap > 65535) return ORBM_E_INVALID;
+    MHIPCHK(hipSetDevice(m->device));
+    int n2 = 64; while (n2 < cap) n2 <<= 1;
+    if ((size_t)n2 * 4 > 150 * 1024) { set_merr("too many keypoints per frame for the LDS sort"); return ORBM_E_CAPACITY; }
+    if (n2 * 4 > 48 * 1024) MHIPCHK(hipFuncSetAttribute((const void*)k_grid_build_batch, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 4));
+    MHIPCHK(hipEventRecord(m->e2, m->stream));
+    m->gridFirst = true;                                                    // orbm_last_timing then spans grid build + the next kernel
+    hipLaunchKernelGGL(k_grid_build_batch, dim3(nframes), dim3(256), (size_t)n2 * 4, m->stream, (const KpIn*)kps, counts, cap, n2,
+                       min_x, min_y, inv_w, inv_h, grid_start, grid_idx);
+    MHIPCHK(hipGetLastError());
+    return ORBM_OK;
+}
+
+int orbm_track_window_batch_async(orbm_t* m, const orbm_kp_t* kps, const uint8_t* desc, const int32_t* counts, int cap,
+                                  const int32_t* grid_start, const int32_t* grid_idx,
+                                  float min_x, float min_y, float inv_w, float inv_h,
+                                  int q_first, int t_first, int npairs, float th, const float* sf, int nlevels,
+                                  float dx, float dy, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist) {
+    if (!m || !kps || !desc || !counts || !grid_start || !grid_idx || !best_idx || !best_dist || !second_dist || npairs < 1 ||
+        nlevels < 1 || nlevels > 12 || !sf) return ORBM_E_INVALID;
+    MHIPCHK(hipSetDevice(m->device));
+    ScaleTab st;
+    for (int i = 0; i < 12; ++i) st.sf[i] = i < nlevels ? sf[i] : sf[nlevels - 1];
+    MHIPCHK(hipEventRecord(m->e0, m->stream));
+    hipLaunchKernelGGL(k_track_window, dim3((cap + 3) / 4, npairs), dim3(256), 0, m->stream, (const KpIn*)kps, desc, counts, cap,
+                       grid_start, grid_idx, min_x, min_y, inv_w, inv_h, q_first, t_first, th, st, dx, dy, best_idx, best_dist, second_dist);
+    MHIPCHK(hipEventRecord(m->e1, m->stream));
+    MHIPCHK(hipGetLastError());
+    m->timed = true;
+    return ORBM_OK;
 }
 
 int orbm_search_by_bow_kf(orbm_t* m, int n1, const orbm_kp_t* kps1, const uint8_t* desc1, const uint8_t* good1,

@@ -317,4 +317,130 @@ __global__ __launch_bounds__(256) void k_stereo(const KpIn* __restrict__ kl, con
     if (lane == 0) { uright[iL] = ur_out; depth[iL] = depth_out; bestSad[iL] = sad_out; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Batched, device-resident forms (frame-to-frame tracking with no host round trip).
+// k_grid_build_batch: one workgroup per frame of an extractor result block [nframes][cap].
+// k_track_window: wave per keypoint of the query frame; window = (x+dx, y+dy) +- th*scale[octave], levels
+// [octave-1, octave+1] in the train frame's grid (the mono SearchByProjection window, ORBmatcher.cc:2543-2549);
+// writes the first-minimum best and the runner-up (strict <, candidate order) -- the claim-free part of the search.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grid_build_batch(const KpIn* __restrict__ kps, const int* __restrict__ counts, int cap, int n2,
+                                                          float min_x, float min_y, float inv_w, float inv_h,
+                                                          int* __restrict__ grid_start, int* __restrict__ grid_idx) {
+    extern __shared__ unsigned int keys[];
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const int n = min(counts[frame], cap);
+    const KpIn* kp = kps + (size_t)frame * cap;
+    __shared__ int s_placed;
+    if (tid == 0) s_placed = 0;
+    __syncthreads();
+    for (int i = tid; i < n2; i += 256) {
+        unsigned int key = 0xFFFFFFFFu;
+        if (i < n) {
+            const int px = (int)roundf((kp[i].x - min_x) * inv_w);
+            const int py = (int)roundf((kp[i].y - min_y) * inv_h);
+            if (px >= 0 && px < 64 && py >= 0 && py < 48) { key = ((unsigned)(px * 48 + py) << 16) | (unsigned)i; atomicAdd(&s_placed, 1); }
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned int a = keys[i], b = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    const int np = s_placed;
+    int* gi = grid_idx + (size_t)frame * cap;
+    int* gs = grid_start + (size_t)frame * (64 * 48 + 1);
+    for (int i = tid; i < np; i += 256) gi[i] = (int)(keys[i] & 0xFFFFu);
+    for (int c = tid; c <= 64 * 48; c += 256) {
+        const unsigned int target = (unsigned)c << 16;
+        int lo = 0, hi = np;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < target) lo = mid + 1; else hi = mid; }
+        gs[c] = lo;
+    }
+}
+
+struct ScaleTab { float sf[12]; };
+
+__global__ __launch_bounds__(256) void k_track_window(const KpIn* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                      const int* __restrict__ counts, int cap, const int* __restrict__ grid_start,
+                                                      const int* __restrict__ grid_idx, float min_x, float min_y, float inv_w, float inv_h,
+                                                      int q_first, int t_first, float th, ScaleTab st, float dx, float dy,
+                                                      int* __restrict__ best_idx, int* __restrict__ best_dist,
+                                                      int* __restrict__ second_dist) {
+    const int lane = threadIdx.x & 63;
+    const int pair = blockIdx.y;
+    const int qf = q_first + pair, tf = t_first + pair;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= min(counts[qf], cap)) return;
+    const KpIn kq = kps[(size_t)qf * cap + q];
+    const KpIn* kt = kps + (size_t)tf * cap;
+    const uint8_t* dt = desc + (size_t)tf * cap * 32;
+    const int* gs = grid_start + (size_t)tf * (64 * 48 + 1);
+    const int* gi = grid_idx + (size_t)tf * cap;
+    const float x = kq.x + dx, y = kq.y + dy, r = th * st.sf[kq.octave];
+    const int minLevel = kq.octave - 1, maxLevel = kq.octave + 1;
+    unsigned int best = 0xFFFFFFFFu;                                        // (dist << 16 | order): first minimum in candidate order
+    int second = 256, bestk = -1;
+    const int nMinCellX = max(0, (int)floorf((x - min_x - r) * inv_w));
+    const int nMaxCellX = min(63, (int)ceilf((x - min_x + r) * inv_w));
+    const int nMinCellY = max(0, (int)floorf((y - min_y - r) * inv_h));
+    const int nMaxCellY = min(47, (int)ceilf((y - min_y + r) * inv_h));
+    int ord0 = 0;
+    int bd = 256, bk = -1, sd = 256;                                        // per-lane partials
+    unsigned int bo = 0xFFFFFFFFu;
+    if (nMinCellX < 64 && nMaxCellX >= 0 && nMinCellY < 48 && nMaxCellY >= 0) {
+        const uint4* qp = (const uint4*)(desc + ((size_t)qf * cap + q) * 32);
+        const uint4 qlo = qp[0], qhi = qp[1];
+        const u64 a[4] = {(u64)qlo.x | ((u64)qlo.y << 32), (u64)qlo.z | ((u64)qlo.w << 32),
+                          (u64)qhi.x | ((u64)qhi.y << 32), (u64)qhi.z | ((u64)qhi.w << 32)};
+        for (int ix = nMinCellX; ix <= nMaxCellX; ++ix) {
+            const int j0 = gs[ix * 48 + nMinCellY], j1 = gs[ix * 48 + nMaxCellY + 1];
+            for (int jb = j0; jb < j1; jb += 64) {
+                const int j = jb + lane;
+                if (j < j1) {
+                    const int k = gi[j];
+                    const KpIn kp = kt[k];
+                    bool ok = !(kp.octave < minLevel) && !(kp.octave > maxLevel);   // bCheckLevels is true here (maxLevel >= 0)
+                    if (!(fabsf(kp.x - x) < r && fabsf(kp.y - y) < r)) ok = false;
+                    if (ok) {
+                        const uint4* tp = (const uint4*)(dt + (size_t)k * 32);
+                        const uint4 lo = tp[0], hi = tp[1];
+                        const int d = ham256(a, (u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
+                                             (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32));
+                        const unsigned int key = ((unsigned)d << 20) | (unsigned)(ord0 + (j - j0));   // order within the whole sweep
+                        if (key < bo) { sd = bd; bo = key; bd = d; bk = k; }
+                        else if (d < sd) sd = d;
+                    }
+                }
+            }
+            ord0 += j1 - j0;
+        }
+    }
+    // wave merge of (best key, runner-up distance): runner-up = min over all candidates except the winner
+    unsigned int wbest = bo;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wbest = min(wbest, (unsigned)__shfl_xor((int)wbest, o));
+    int cand2 = (bo == wbest) ? sd : bd;                                     // lanes that lost contribute their own best
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand2 = min(cand2, __shfl_xor(cand2, o));
+    best = wbest; second = cand2;
+    const unsigned long long who = __ballot(bo == wbest && wbest != 0xFFFFFFFFu);
+    if (who) bestk = __shfl(bk, __ffsll((long long)who) - 1);
+    if (lane == 0) {
+        const size_t o = (size_t)pair * cap + q;
+        best_idx[o] = bestk;
+        best_dist[o] = bestk < 0 ? 256 : (int)(best >> 20);
+        second_dist[o] = second;
+    }
+}
+
 }  // namespace orbmk

@@ -251,3 +251,44 @@ def test_searches_handle_empty_inputs(pkg, scene):
     assert n == 0 and np.all(match == -1)
     n, m12, _ = m.SearchForInitialization(empty, full, np.zeros((0, 2), np.float32), 100, 0.9)
     assert n == 0 and len(m12) == 0
+
+
+def test_device_resident_tracking_window_batch(pkg, oracle, synth):
+    """Batched device-resident grid build + tracking window (no host round trip) against the host entry points that are
+    themselves pinned to the oracle: same grids, same first-minimum best / runner-up per keypoint."""
+    import ctypes as C
+    imgs = [synth.gen_image(752, 480, 500 + i) for i in range(4)]
+    ex = pkg.ORBextractor(1000, max_size=(752, 480), max_batch=4)
+    res = ex.extract_batch(imgs, [(0, 1000)] * 4)
+    m = pkg.ORBmatcher(0.9)
+    L = pkg.lib()
+    r = ex.result_device(); cap = r["cap"]
+    gs = pkg.DeviceBuffer(4 * 3073 * 4); gi = pkg.DeviceBuffer(4 * cap * 4)
+    inv_w = np.float32(64) / np.float32(752); inv_h = np.float32(48) / np.float32(480)
+    assert L.orbm_grid_build_batch_async(m.h, r["kps"], r["counts"], 4, cap, 0.0, 0.0, float(inv_w), float(inv_h), gs.ptr, gi.ptr) == 0
+    bi = pkg.DeviceBuffer(3 * cap * 4); bd = pkg.DeviceBuffer(3 * cap * 4); sd = pkg.DeviceBuffer(3 * cap * 4)
+    sf = ex.GetScaleFactors()
+    assert L.orbm_track_window_batch_async(m.h, r["kps"], r["desc"], r["counts"], cap, gs.ptr, gi.ptr, 0.0, 0.0, float(inv_w), float(inv_h),
+                                           1, 0, 3, 15.0, sf.ctypes.data_as(C.c_void_p), 8, 2.0, -1.0, bi.ptr, bd.ptr, sd.ptr) == 0
+    m.sync()
+    g_start = gs.download(np.int32, 4 * 3073).reshape(4, 3073); g_idx = gi.download(np.int32, 4 * cap).reshape(4, cap)
+    best_i = bi.download(np.int32, 3 * cap).reshape(3, cap); best_d = bd.download(np.int32, 3 * cap).reshape(3, cap)
+    sec_d = sd.download(np.int32, 3 * cap).reshape(3, cap)
+    OM = oracle._oracle_matcher_class()()
+    for p in range(3):
+        (_, kq, dq), (_, kt, dt) = res[p + 1], res[p]
+        fo = pkg.FrameView(kt, dt, 752, 480, backend=OM)
+        assert np.array_equal(g_start[p], fo.grid_start) and np.array_equal(g_idx[p, :fo.placed], fo.grid_idx[:fo.placed])
+        f = pkg.FrameView(kt, dt, 752, 480, backend=m)
+        qr = (np.float32(15.0) * sf[kq["octave"]]).astype(np.float32)
+        cnt, idx, dist = m.window_candidates(f, kq["x"] + np.float32(2.0), kq["y"] + np.float32(-1.0), qr, kq["octave"] - 1, kq["octave"] + 1,
+                                             dq, cap=f.n)
+        for q in range(len(kq)):
+            if cnt[q] == 0:
+                assert best_i[p, q] == -1 and best_d[p, q] == 256
+                continue
+            d = dist[q, :cnt[q]]
+            b = int(np.argmin(d))                                   # first minimum in candidate order
+            assert best_i[p, q] == idx[q, b] and best_d[p, q] == d[b]
+            rest = np.delete(d, b)
+            assert sec_d[p, q] == (int(rest.min()) if len(rest) else 256)
