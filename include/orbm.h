@@ -181,6 +181,24 @@ int orbm_track_window_batch_async(orbm_t*, const orbm_kp_t* kps, const uint8_t* 
                                   int q_first, int t_first, int npairs, float th, const float* scale_factors_host, int nlevels,
                                   float dx, float dy, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);
 
+/* ---- DBoW2 vocabulary transform (Frame::ComputeBoW, Frame.cc:905-918;
+ * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1125-1262, FORB::distance FORB.cpp:81-101) ----
+ * The tree lives in HBM; orbm_bow_transform descends it for n descriptors (host pointers) and returns per feature the
+ * word id, the node id `levelsup` levels above the leaves (the SearchByBoW bucket) and the word weight (0 = stopped).
+ * orbm_bow_vectors assembles BowVector (TF-IDF, L1-normalised: the ORBvoc configuration) and FeatureVector (CSR) on the
+ * host exactly as the std::map based classes do. */
+typedef struct orbm_vocab orbm_vocab_t;
+int orbm_vocab_load_text(orbm_t*, orbm_vocab_t** out, const char* path);     /* loadFromTextFile, :1338-1440 */
+int orbm_vocab_create(orbm_t*, orbm_vocab_t** out, int k, int L, int nnodes, const int32_t* parent, const uint8_t* is_leaf,
+                      const uint8_t* desc, const double* weight);            /* node 0 = root; ids in file order */
+void orbm_vocab_destroy(orbm_vocab_t*);
+int orbm_vocab_info(const orbm_vocab_t*, int* k, int* L, int* nnodes, int* nwords);
+int orbm_bow_transform(orbm_t*, const orbm_vocab_t*, const uint8_t* desc, int n, int levelsup,
+                       int32_t* word_id, int32_t* node_id, double* weight);
+int orbm_bow_vectors(int n, const int32_t* word_id, const int32_t* node_id, const double* weight,
+                     int32_t* bow_ids, double* bow_vals, int* nbow,
+                     int32_t* fv_nodes, int32_t* fv_start, int32_t* fv_idx, int* nfv);
+
 /* M15 Frame::ComputeStereoMatches (Frame.cc:1027-1276).  left/right are orbx_t* extractor handles (include/orbx.h)
  * on the same device whose LAST call produced the two keypoint sets: their device-resident pyramids supply the
  * 11x11 SAD windows (mvImagePyramid, include/ORBextractor.h:83).  frame_l/frame_r select the batch slot.

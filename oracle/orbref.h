@@ -156,6 +156,20 @@ int orbref_search_by_sim3(const orbref_frame_t* kf1, const orbref_frame_t* kf2, 
                           const uint8_t* valid1, const float* u1, const float* v1, const int32_t* level1, const uint8_t* qdesc1,
                           const uint8_t* valid2, const float* u2, const float* v2, const int32_t* level2, const uint8_t* qdesc2,
                           float th, int32_t* matches12);
+/* ---- DBoW2 (vendored: Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h, FORB.cpp) ----
+ * loadFromTextFile (:1338-1440) + transform (:1125-1262): per feature the word id, the node id `levelsup` levels above
+ * the leaves and the word weight (0 = stopped).  Returns 0 or -1 (bad file). */
+typedef struct orbref_vocab orbref_vocab_t;
+orbref_vocab_t* orbref_vocab_load_text(const char* path);
+void orbref_vocab_destroy(orbref_vocab_t*);
+int orbref_vocab_info(const orbref_vocab_t*, int* k, int* L, int* nnodes, int* nwords);
+int orbref_bow_transform(const orbref_vocab_t*, const uint8_t* desc, int n, int levelsup,
+                         int32_t* word_id, int32_t* node_id, double* weight);
+/* BowVector (TF-IDF weighting, L1 normalisation: the ORBvoc configuration) + FeatureVector from the per-feature
+ * results, as Frame::ComputeBoW builds them (Frame.cc:905-918).  bow_ids/bow_vals: capacity n; fv_*: CSR. */
+int orbref_bow_vectors(int n, const int32_t* word_id, const int32_t* node_id, const double* weight,
+                       int32_t* bow_ids, double* bow_vals, int* nbow,
+                       int32_t* fv_nodes, int32_t* fv_start, int32_t* fv_idx, int* nfv);
 /* Frame::ComputeStereoMatches (Frame.cc:1027-1276).  Pyramids are those of the two extractors' last call. */
 int orbref_stereo_matches(const orbref_t* left, const orbref_t* right,
                           int nl, const orbref_kp_t* kl, const uint8_t* dl, int nr, const orbref_kp_t* kr, const uint8_t* dr,

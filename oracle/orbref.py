@@ -217,3 +217,38 @@ def _oracle_matcher_class():
             return n, ur[:len(kl)], dp[:len(kl)]
 
     return OracleMatcher
+
+
+# ---- DBoW2 vocabulary transform (oracle side) ----
+class Vocabulary:
+    def __init__(self, path):
+        L = lib()
+        L.orbref_vocab_load_text.restype = C.c_void_p
+        L.orbref_vocab_load_text.argtypes = [C.c_char_p]
+        L.orbref_vocab_destroy.argtypes = [C.c_void_p]
+        L.orbref_vocab_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+        L.orbref_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orbref_bow_vectors.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int),
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        self.L = L
+        self.h = L.orbref_vocab_load_text(path.encode())
+        assert self.h, "oracle could not load " + path
+
+    def info(self):
+        v = [C.c_int() for _ in range(4)]
+        self.L.orbref_vocab_info(self.h, *[C.byref(x) for x in v])
+        return dict(zip(["k", "L", "nnodes", "nwords"], [x.value for x in v]))
+
+    def transform(self, desc, levelsup=4):
+        import importlib
+        pkg = importlib.import_module("orb-slam3_amd")
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); n = desc.shape[0]
+        w = np.zeros(max(n, 1), np.int32); nd = np.zeros(max(n, 1), np.int32); wt = np.zeros(max(n, 1), np.float64)
+        self.L.orbref_bow_transform(self.h, _p(desc), n, levelsup, _p(w), _p(nd), _p(wt))
+        return pkg.bow_vectors(self.L.orbref_bow_vectors, n, w[:n], nd[:n], wt[:n]) + (w[:n], nd[:n], wt[:n])
+
+    def __del__(self):
+        try:
+            self.L.orbref_vocab_destroy(self.h)
+        except Exception:
+            pass

@@ -560,6 +560,13 @@ def _install_search():
     L.orbm_track_window_batch_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float,
                                                 C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orbm_vocab_load_text.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_char_p]
+    L.orbm_vocab_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orbm_vocab_destroy.argtypes = [C.c_void_p]
+    L.orbm_vocab_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+    L.orbm_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orbm_bow_vectors.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
     ORBmatcher.window_candidates = window_candidates
     ORBmatcher.ComputeStereoMatches = stereo_matches
 
@@ -568,7 +575,8 @@ EXPORTS += ["orbm_grid_build", "orbm_window_candidates", "orbm_search_by_project
             "orbm_search_for_initialization", "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_stereo_matches",
             "orbm_search_by_projection_kf", "orbm_search_by_bow_kf", "orbm_search_for_triangulation_legacy",
             "orbm_search_by_projection_sim3", "orbm_fuse", "orbm_search_by_sim3",
-            "orbm_grid_build_batch_async", "orbm_track_window_batch_async"]
+            "orbm_grid_build_batch_async", "orbm_track_window_batch_async",
+            "orbm_vocab_load_text", "orbm_vocab_create", "orbm_vocab_destroy", "orbm_vocab_info", "orbm_bow_transform", "orbm_bow_vectors"]
 _orig_lib = lib
 _search_ready = False
 
@@ -580,3 +588,39 @@ def lib():                                         # noqa: F811  (binds the sear
         _search_ready = True
         _install_search()
     return L
+
+
+class ORBVocabulary:
+    """DBoW2 ORB vocabulary resident in HBM (include/ORBVocabulary.h typedef; TemplatedVocabulary.h)."""
+
+    def __init__(self, matcher, path):
+        self.L = lib(); self.m = matcher
+        h = C.c_void_p()
+        _chk(self.L.orbm_vocab_load_text(matcher.h, C.byref(h), path.encode()), "orbm_vocab_load_text")
+        self.h = h
+
+    def info(self):
+        v = [C.c_int() for _ in range(4)]
+        self.L.orbm_vocab_info(self.h, *[C.byref(x) for x in v])
+        return dict(zip(["k", "L", "nnodes", "nwords"], [x.value for x in v]))
+
+    def transform(self, desc, levelsup=4):
+        """Frame::ComputeBoW: returns (BowVector ids, values), FeatureVector CSR (nodes, start, idx), per-feature arrays."""
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); n = desc.shape[0]
+        w = np.zeros(max(n, 1), np.int32); nd = np.zeros(max(n, 1), np.int32); wt = np.zeros(max(n, 1), np.float64)
+        _chk(self.L.orbm_bow_transform(self.m.h, self.h, _p(desc), n, levelsup, _p(w), _p(nd), _p(wt)), "orbm_bow_transform")
+        return bow_vectors(self.L.orbm_bow_vectors, n, w[:n], nd[:n], wt[:n]) + (w[:n], nd[:n], wt[:n])
+
+    def __del__(self):
+        try:
+            self.L.orbm_vocab_destroy(self.h)
+        except Exception:
+            pass
+
+
+def bow_vectors(fn, n, w, nd, wt):
+    w = np.ascontiguousarray(w, np.int32); nd = np.ascontiguousarray(nd, np.int32); wt = np.ascontiguousarray(wt, np.float64)
+    bi = np.zeros(max(n, 1), np.int32); bv = np.zeros(max(n, 1), np.float64); nb = C.c_int()
+    fn_ = np.zeros(max(n, 1), np.int32); fs = np.zeros(max(n, 1) + 1, np.int32); fi = np.zeros(max(n, 1), np.int32); nf = C.c_int()
+    fn(n, _p(w), _p(nd), _p(wt), _p(bi), _p(bv), C.byref(nb), _p(fn_), _p(fs), _p(fi), C.byref(nf))
+    return (bi[:nb.value], bv[:nb.value]), (fn_[:nf.value], fs[:nf.value + 1], fi[:fs[nf.value]])

@@ -728,6 +728,142 @@ int orbm_track_window_batch_async(orbm_t* m, const orbm_kp_t* kps, const uint8_t
     return ORBM_OK;
 }
 
+// ---- DBoW2 vocabulary ----
+struct orbm_vocab {
+    int k = 0, L = 0, nnodes = 0, nwords = 0, device = 0;
+    int *dChildStart = nullptr, *dChildIdx = nullptr, *dWord = nullptr;
+    uint8_t* dDesc = nullptr;
+    double* dWeight = nullptr;
+};
+
+void orbm_vocab_destroy(orbm_vocab_t* v) {
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    void* ps[] = {v->dChildStart, v->dChildIdx, v->dWord, v->dDesc, v->dWeight};
+    for (void* p : ps) if (p) (void)hipFree(p);
+    delete v;
+}
+
+int orbm_vocab_create(orbm_t* m, orbm_vocab_t** out, int k, int L, int nnodes, const int32_t* parent, const uint8_t* is_leaf,
+                      const uint8_t* desc, const double* weight) {
+    if (!m || !out || nnodes < 2 || !parent || !is_leaf || !desc || !weight) return ORBM_E_INVALID;
+    *out = nullptr;
+    // children lists in node-id order, word ids in leaf order: what loadFromTextFile builds (:1385-1420)
+    std::vector<int> cstart(nnodes + 1, 0), cidx(nnodes - 1), word(nnodes, 0);
+    for (int i = 1; i < nnodes; ++i) {
+        if (parent[i] < 0 || parent[i] >= i) { set_merr("vocabulary node %d has parent %d (must precede it)", i, parent[i]); return ORBM_E_INVALID; }
+        cstart[parent[i] + 1]++;
+    }
+    for (int i = 0; i < nnodes; ++i) cstart[i + 1] += cstart[i];
+    std::vector<int> fill(cstart.begin(), cstart.end() - 1);
+    int nwords = 0;
+    for (int i = 1; i < nnodes; ++i) { cidx[fill[parent[i]]++] = i; if (is_leaf[i]) word[i] = nwords++; }
+    for (int i = 1; i < nnodes; ++i)
+        if ((cstart[i + 1] == cstart[i]) != (is_leaf[i] != 0)) { set_merr("vocabulary node %d: leaf flag disagrees with its children", i); return ORBM_E_INVALID; }
+    MHIPCHK(hipSetDevice(m->device));
+    orbm_vocab* v = new orbm_vocab;
+    v->k = k; v->L = L; v->nnodes = nnodes; v->nwords = nwords; v->device = m->device;
+    bool ok = hipMalloc((void**)&v->dChildStart, sizeof(int) * (nnodes + 1)) == hipSuccess && hipMalloc((void**)&v->dChildIdx, sizeof(int) * nnodes) == hipSuccess &&
+              hipMalloc((void**)&v->dWord, sizeof(int) * nnodes) == hipSuccess && hipMalloc((void**)&v->dDesc, (size_t)32 * nnodes) == hipSuccess &&
+              hipMalloc((void**)&v->dWeight, sizeof(double) * nnodes) == hipSuccess;
+    ok = ok && hipMemcpy(v->dChildStart, cstart.data(), sizeof(int) * (nnodes + 1), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->dChildIdx, cidx.data(), sizeof(int) * (nnodes - 1), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->dWord, word.data(), sizeof(int) * nnodes, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->dDesc, desc, (size_t)32 * nnodes, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->dWeight, weight, sizeof(double) * nnodes, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { set_merr("vocabulary upload failed"); orbm_vocab_destroy(v); return ORBM_E_HIP; }
+    *out = v;
+    return ORBM_OK;
+}
+
+int orbm_vocab_load_text(orbm_t* m, orbm_vocab_t** out, const char* path) {
+    if (!m || !out || !path) return ORBM_E_INVALID;
+    FILE* f = fopen(path, "r");
+    if (!f) { set_merr("cannot open vocabulary %s", path); return ORBM_E_INVALID; }
+    int k = 0, L = 0, n1 = 0, n2 = 0;
+    if (fscanf(f, "%d %d %d %d", &k, &L, &n1, &n2) != 4 || k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3) {
+        fclose(f); set_merr("vocabulary %s: not a correct text file", path); return ORBM_E_INVALID;       // :1359-1363
+    }
+    std::vector<int> parent(1, 0);
+    std::vector<uint8_t> leaf(1, 0), desc(32, 0);
+    std::vector<double> weight(1, 0.0);
+    for (;;) {
+        int pid, isleaf;
+        if (fscanf(f, "%d %d", &pid, &isleaf) != 2) break;
+        uint8_t d[32];
+        bool good = true;
+        for (int i = 0; i < 32; ++i) { int b; if (fscanf(f, "%d", &b) != 1) { good = false; break; } d[i] = (uint8_t)b; }
+        double w;
+        if (!good || fscanf(f, "%lf", &w) != 1) break;
+        parent.push_back(pid); leaf.push_back(isleaf > 0); weight.push_back(w);
+        desc.insert(desc.end(), d, d + 32);
+    }
+    fclose(f);
+    return orbm_vocab_create(m, out, k, L, (int)parent.size(), parent.data(), leaf.data(), desc.data(), weight.data());
+}
+
+int orbm_vocab_info(const orbm_vocab_t* v, int* k, int* L, int* nnodes, int* nwords) {
+    if (!v) return ORBM_E_INVALID;
+    *k = v->k; *L = v->L; *nnodes = v->nnodes; *nwords = v->nwords;
+    return ORBM_OK;
+}
+
+int orbm_bow_transform(orbm_t* m, const orbm_vocab_t* v, const uint8_t* desc, int n, int levelsup,
+                       int32_t* word_id, int32_t* node_id, double* weight) {
+    if (!m || !v || n < 0 || (n > 0 && (!desc || !word_id || !node_id || !weight))) return ORBM_E_INVALID;
+    if (n == 0) return ORBM_OK;
+    if (v->device != m->device) { set_merr("vocabulary lives on another device"); return ORBM_E_INVALID; }
+    MHIPCHK(hipSetDevice(m->device));
+    DevBuf dd, dw, dn, dwt;
+    UP(dd, desc, (size_t)32 * n); AL(dw, sizeof(int) * n); AL(dn, sizeof(int) * n); AL(dwt, sizeof(double) * n);
+    m->gridFirst = false;
+    MHIPCHK(hipEventRecord(m->e0, m->stream));
+    hipLaunchKernelGGL(k_bow_transform, dim3((n + 255) / 256), dim3(256), 0, m->stream, dd.as<uint8_t>(), n, v->dChildStart, v->dChildIdx,
+                       v->dDesc, v->dWord, v->dWeight, v->L, levelsup, dw.as<int>(), dn.as<int>(), dwt.as<double>());
+    MHIPCHK(hipEventRecord(m->e1, m->stream));
+    m->timed = true;
+    MHIPCHK(hipGetLastError());
+    MHIPCHK(hipStreamSynchronize(m->stream));
+    MHIPCHK(hipMemcpy(word_id, dw.p, sizeof(int) * n, hipMemcpyDeviceToHost));
+    MHIPCHK(hipMemcpy(node_id, dn.p, sizeof(int) * n, hipMemcpyDeviceToHost));
+    MHIPCHK(hipMemcpy(weight, dwt.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return ORBM_OK;
+}
+
+int orbm_bow_vectors(int n, const int32_t* word_id, const int32_t* node_id, const double* weight,
+                     int32_t* bow_ids, double* bow_vals, int* nbow,
+                     int32_t* fv_nodes, int32_t* fv_start, int32_t* fv_idx, int* nfv) {
+    // BowVector::addWeight in feature order (BowVector.cpp:34-46), then L1 normalisation in word order (:62-84);
+    // FeatureVector::addFeature (FeatureVector.cpp:34-46).  Sorted vectors instead of std::map, same summation order.
+    std::vector<std::pair<int, int>> byWord, byNode;             // (key, feature)
+    for (int i = 0; i < n; ++i) if (weight[i] > 0) { byWord.push_back(std::make_pair(word_id[i], i)); byNode.push_back(std::make_pair(node_id[i], i)); }
+    std::stable_sort(byWord.begin(), byWord.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+    std::stable_sort(byNode.begin(), byNode.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+    int b = 0;
+    for (size_t i = 0; i < byWord.size();) {
+        size_t j = i;
+        double acc = weight[byWord[i].second];
+        for (j = i + 1; j < byWord.size() && byWord[j].first == byWord[i].first; ++j) acc += weight[byWord[j].second];
+        bow_ids[b] = byWord[i].first; bow_vals[b] = acc; ++b;
+        i = j;
+    }
+    double norm = 0.0;
+    for (int i = 0; i < b; ++i) norm += fabs(bow_vals[i]);
+    if (norm > 0.0) for (int i = 0; i < b; ++i) bow_vals[i] /= norm;
+    *nbow = b;
+    int c = 0, o = 0;
+    for (size_t i = 0; i < byNode.size();) {
+        size_t j = i;
+        fv_nodes[c] = byNode[i].first; fv_start[c] = o;
+        for (j = i; j < byNode.size() && byNode[j].first == byNode[i].first; ++j) fv_idx[o++] = byNode[j].second;
+        ++c;
+        i = j;
+    }
+    fv_start[c] = o;
+    *nfv = c;
+    return ORBM_OK;
+}
+
 int orbm_search_by_bow_kf(orbm_t* m, int n1, const orbm_kp_t* kps1, const uint8_t* desc1, const uint8_t* good1,
                           int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
                           int n2, const orbm_kp_t* kps2, const uint8_t* desc2, const uint8_t* good2,

@@ -443,4 +443,44 @@ __global__ __launch_bounds__(256) void k_track_window(const KpIn* __restrict__ k
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_bow_transform: DBoW2 TemplatedVocabulary::transform (TemplatedVocabulary.h:1196-1262) for a batch of
+// descriptors.  One thread per descriptor walks the k-ary tree: at every level the child with the smallest
+// Hamming distance (first minimum, strict <) is taken; the node reached at level L-levelsup is recorded.
+// Children of a node are contiguous (CSR), node descriptors are rows of one array.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bow_transform(const uint8_t* __restrict__ desc, int n, const int* __restrict__ child_start,
+                                                       const int* __restrict__ child_idx, const uint8_t* __restrict__ ndesc,
+                                                       const int* __restrict__ nword, const double* __restrict__ nweight,
+                                                       int L, int levelsup, int* __restrict__ word_id, int* __restrict__ node_id,
+                                                       double* __restrict__ weight) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint4* qp = (const uint4*)(desc + (size_t)i * 32);
+    const uint4 qlo = qp[0], qhi = qp[1];
+    const u64 a[4] = {(u64)qlo.x | ((u64)qlo.y << 32), (u64)qlo.z | ((u64)qlo.w << 32),
+                      (u64)qhi.x | ((u64)qhi.y << 32), (u64)qhi.z | ((u64)qhi.w << 32)};
+    const int nid_level = L - levelsup;
+    int nid = 0, final_id = 0, level = 0;
+    for (;;) {
+        const int c0 = child_start[final_id], c1 = child_start[final_id + 1];
+        if (c0 == c1) break;                                                    // leaf
+        ++level;
+        int best = 1 << 20, bid = 0;
+        for (int c = c0; c < c1; ++c) {
+            const int id = child_idx[c];
+            const uint4* tp = (const uint4*)(ndesc + (size_t)id * 32);
+            const uint4 lo = tp[0], hi = tp[1];
+            const int d = ham256(a, (u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
+                                 (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32));
+            if (d < best) { best = d; bid = id; }
+        }
+        final_id = bid;
+        if (level == nid_level) nid = final_id;
+    }
+    word_id[i] = nword[final_id];
+    weight[i] = nweight[final_id];
+    node_id[i] = nid;
+}
+
 }  // namespace orbmk
