@@ -445,10 +445,10 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     o->lastL0Pitch = l0pitch;
     o->ev = o->evr[o->nEnq % orbx::kRing];
     ++o->nEnq;
-    // Two HIP streams (events order them): the resize chain + blur are latency-bound and leave the VALUs idle, FAST is
-    // VALU-bound -- so level-0 FAST (needs no resize) runs beside the resize chain and levels 1..7 beside the blur.
+    // Two HIP streams (events order them): FAST is VALU-bound, the resize chain is latency-bound and the quadtree is
+    // LDS-latency-bound -- so level-0 FAST (needs no resize) runs beside the resize chain and the blur beside the quadtree.
     //   s0: FAST(L0) --wait pyramid--> FAST(L1..) -> quadtree -> slots --wait blur--> orientation+descriptors
-    //   s1: resize L1..L7 -> [pyramid ready] -> blur -> [blur ready]
+    //   s1: resize L1..L7 -> [pyramid ready] --wait FAST--> blur -> [blur ready]
     hipStream_t s1 = o->serial ? o->stream : o->stream2;          // ORBX_SERIAL=1: single stream, clean per-kernel timings
     HIPCHK(hipEventRecord(o->ev[0], st));
     HIPCHK(hipStreamWaitEvent(s1, o->ev[0], 0));                 // inputs uploaded; previous batch's readers of the pyramid are done
@@ -464,9 +464,6 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
         }
     }
     HIPCHK(hipEventRecord(o->ev[8], s1));                        // pyramid ready
-    hipLaunchKernelGGL(k_blur2, dim3((unsigned)(o->tiles.size() + 3) / 4, nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
-                       o->dTiles, (int)o->tiles.size(), o->blurSel);
-    HIPCHK(hipEventRecord(o->ev[9], s1));                        // blur ready
     if (o->fastV1) {
         HIPCHK(hipStreamWaitEvent(st, o->ev[8], 0));
         HIPCHK(hipEventRecord(o->ev[1], st));
@@ -485,6 +482,12 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
                                o->dCells, o->dStrips + n0, o->dCandCnt, o->dCandEnt, o->dErr, o->f3Tile, o->f3Qcap);
     }
     HIPCHK(hipEventRecord(o->ev[2], st));
+    // blur (VALU + HBM) runs beside the quadtree (LDS-latency bound), not beside FAST (VALU bound)
+    if (!o->serial) HIPCHK(hipStreamWaitEvent(s1, o->ev[2], 0));
+    HIPCHK(hipEventRecord(o->ev[11], s1));
+    hipLaunchKernelGGL(k_blur2, dim3((unsigned)(o->tiles.size() + 3) / 4, nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
+                       o->dTiles, (int)o->tiles.size(), o->blurSel);
+    HIPCHK(hipEventRecord(o->ev[9], s1));                        // blur ready
     if (o->qtV1)
         hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, nimg), dim3(256), o->qtLds, st, g, o->dCells, o->dCandCnt, o->dCandEnt,
                            o->dKpNode, o->dSel, o->dSelCnt, o->dErr);
@@ -653,7 +656,7 @@ static int timings_of(orbx* o, hipEvent_t* ev, float* ms7) {
     ms7[1] = o->fastV1 ? f1 : f0 + f1;
     HIPCHK(hipEventElapsedTime(&ms7[2], ev[2], ev[3]));
     HIPCHK(hipEventElapsedTime(&ms7[3], ev[3], ev[4]));
-    HIPCHK(hipEventElapsedTime(&ms7[4], ev[8], ev[9]));      // blur (stream 2)
+    HIPCHK(hipEventElapsedTime(&ms7[4], ev[11], ev[9]));     // blur (stream 2, beside the quadtree)
     HIPCHK(hipEventElapsedTime(&ms7[5], ev[5], ev[6]));
     HIPCHK(hipEventElapsedTime(&ms7[6], ev[0], ev[6]));
     HIPCHK(hipEventElapsedTime(&ms7[7], ev[0], ev[2]));      // wall span of the pyramid+FAST pass (both streams)

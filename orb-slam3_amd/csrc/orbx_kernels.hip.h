@@ -333,9 +333,12 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
     u8* sc = f3smem + tileBytes;
     StripInfo st = strips[blockIdx.x];
     st.level = (short)__builtin_amdgcn_readfirstlane(st.level);
-    const int frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);              // wave-uniform: per-cell metadata comes through the scalar cache
     u16* q = (u16*)(f3smem + 2 * tileBytes) + wv * qcap;
     const int Pb = st.lp, H = st.h;                                       // lp holds the tile pitch in bytes here
+    // this wave's first cell: fetched now so that its latency hides behind the tile load
+    CellInfo cell0 = cells[st.cell0 + min(wv, st.ncell - 1)];
     int sp;
     const u8* src = level_ptr(g, l0, l0pitch, pyr, frame, st.level, &sp);
     const LevelDesc& L = g.lv[st.level];
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
     __syncthreads();
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int c = wv; c < st.ncell; c += F3_NT / 64) {
-        const CellInfo cell = cells[st.cell0 + c];
+        const CellInfo cell = c == wv ? cell0 : cells[st.cell0 + c];
         const int cx0 = cell.x0 + 3 - st.xal, cx1 = cell.x0 + cell.cw - 3 - st.xal;   // valid columns (tile coords)
         const int vy0 = 3, vy1 = H - 3;
         int n3 = 0;
