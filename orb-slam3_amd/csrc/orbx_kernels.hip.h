@@ -342,16 +342,35 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
     int sp;
     const u8* src = level_ptr(g, l0, l0pitch, pyr, frame, st.level, &sp);
     const LevelDesc& L = g.lv[st.level];
-    {   // tile load: 32 lanes x 16 B per row
+    {   // tile load: 32 lanes x 16 B per row; the loads of 6 row-passes (48 rows at 256 threads) are issued back to back
+        // before the first LDS write (one memory round trip instead of one per pass)
         const int cpr = Pb >> 4;
         const int rowLimit = min((L.w + 15) & ~15, sp);
         const int ck = tid & 31;
-        for (int r = tid >> 5; r < H; r += F3_NT / 32) {
-            if (ck < cpr) {
-                const int gx = st.xal + ck * 16;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (gx < rowLimit) v = gload128(src + (size_t)(st.y0 + r) * sp + gx);
-                *(uint4*)(img + r * Pb + ck * 16) = v;
+        const int gx = st.xal + ck * 16;
+        const bool colOk = ck < cpr;
+        const bool ldOk = colOk && gx < rowLimit;
+        const int RP = F3_NT / 32;
+        uint4 v[6];
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            const int r = (tid >> 5) + p * RP;
+            v[p] = make_uint4(0, 0, 0, 0);
+            if (ldOk && r < H) v[p] = gload128(src + (size_t)(st.y0 + r) * sp + gx);
+        }
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            const int r = (tid >> 5) + p * RP;
+            if (colOk && r < H) {
+                *(uint4*)(img + r * Pb + ck * 16) = v[p];
+                *(uint4*)(sc + r * Pb + ck * 16) = make_uint4(0, 0, 0, 0);
+            }
+        }
+        for (int r = (tid >> 5) + 6 * RP; r < H; r += RP) {               // taller cells (tiny images only)
+            if (colOk) {
+                uint4 t = make_uint4(0, 0, 0, 0);
+                if (gx < rowLimit) t = gload128(src + (size_t)(st.y0 + r) * sp + gx);
+                *(uint4*)(img + r * Pb + ck * 16) = t;
                 *(uint4*)(sc + r * Pb + ck * 16) = make_uint4(0, 0, 0, 0);
             }
         }
