@@ -130,3 +130,19 @@ def test_device_resident_inputs_aligned_and_misaligned(pkg, oracle, synth):
             mono, kps, desc = ex.fetch(i)
             assert mono == want[i][0] and kps.tobytes() == want[i][1].tobytes() and np.array_equal(desc, want[i][2])
         ex.close()
+
+
+def test_ab_reference_kernels_stay_bit_exact(pkg, oracle, synth, monkeypatch):
+    """The simple first-generation kernels (per-cell FAST, lane-0 quadtree, one-keypoint-per-wave descriptors, single
+    stream) are kept as A/B references behind environment switches read at orbx_create: they must give the same bits."""
+    img = synth.gen_image(752, 480, 21)
+    n_ref, kps_ref, desc_ref, mono_ref = oracle.Extractor(1000)(img, (0, 1000))
+    for env in (["ORBX_FAST_V1"], ["ORBX_QT_V1"], ["ORBX_OD_V1"], ["ORBX_SERIAL"], ["ORBX_FAST_V1", "ORBX_QT_V1", "ORBX_OD_V1", "ORBX_SERIAL"]):
+        for e in env:
+            monkeypatch.setenv(e, "1")
+        ex = pkg.ORBextractor(1000, max_size=(752, 480))
+        mono, kps, desc = ex(img, (0, 1000))
+        ex.close()
+        for e in env:
+            monkeypatch.delenv(e)
+        assert mono == mono_ref and kps.tobytes() == kps_ref.tobytes() and np.array_equal(desc, desc_ref), env
