@@ -57,6 +57,12 @@ __device__ __forceinline__ u32 as_u32(us2 v) { return __builtin_bit_cast(u32, v)
 __device__ __forceinline__ us2 pkmin(us2 a, us2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ us2 pkmax(us2 a, us2 b) { return __builtin_elementwise_max(a, b); }
 
+__device__ __forceinline__ u32 mad24(u32 a, u32 b, u32 c) {      // a*b + c on 24-bit operands, one VALU instruction
+    u32 d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // Loads through an explicit global address space: pointers fetched from memory (the per-frame level-0 table)
 // are generic to the compiler, which would emit flat_load + conservative vmcnt(0)/lgkmcnt(0) waits.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1161,8 +1167,11 @@ __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int 
                     u32 packed = 0;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const u32 acc = 18u * (u32)(hw[(k + 1) % 7][i] + hw[k][i]) + 34u * (u32)(hw[(k + 2) % 7][i] + hw[(k + 6) % 7][i]) +
-                                        48u * (u32)(hw[(k + 3) % 7][i] + hw[(k + 5) % 7][i]) + 56u * (u32)hw[(k + 4) % 7][i] + 32768u;
+                        // operands fit 24 bits (row sums <= 2*65280): one v_mad_u32_u24 per tap pair
+                        u32 acc = mad24(56u, (u32)hw[(k + 4) % 7][i], 32768u);
+                        acc = mad24(48u, (u32)(hw[(k + 3) % 7][i] + hw[(k + 5) % 7][i]), acc);
+                        acc = mad24(34u, (u32)(hw[(k + 2) % 7][i] + hw[(k + 6) % 7][i]), acc);
+                        acc = mad24(18u, (u32)(hw[(k + 1) % 7][i] + hw[k][i]), acc);
                         packed |= (acc >> 16) << (8 * i);
                     }
                     if (gc <= gl) *(u32*)(dst + (size_t)(t.y0 + r - 6) * L.pitch + gc * 4) = packed;
