@@ -129,6 +129,29 @@ int orbm_search_by_sim3(orbm_t*, const orbm_frame_t* kf1, const orbm_frame_t* kf
                         const uint8_t* valid2, const float* u2, const float* v2, const int32_t* level2, const uint8_t* qdesc2,
                         float th, int32_t* matches12);
 
+/* ---- fisheye stereo (Nleft != -1): left / right keypoints in separate arrays and grids (mvKeys + mGrid, mvKeysRight +
+ * mGridRight); MapPoint slots [0,Nleft) and [Nleft, Nleft+Nright) are reported as match_l / match_r ---- */
+/* M4 with the right-camera block (ORBmatcher.cc:2615-2680); (ur, vr) = projection into the right camera */
+int orbm_search_by_projection_frame_fisheye(orbm_t*, const orbm_frame_t* cur_l, const orbm_frame_t* cur_r,
+                                            const uint8_t* blocked_l, const uint8_t* blocked_r, const float* scale_factors,
+                                            int nq, const uint8_t* valid, const float* u, const float* v, const float* ur, const float* vr,
+                                            const int32_t* octave, const float* angle, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                            float th, int forward, int backward, int check_ori, int32_t* match_l, int32_t* match_r);
+/* M3 with the right-camera block (ORBmatcher.cc:170-236) and the mvLeftToRightMatch / mvRightToLeftMatch cross
+ * assignments (:152-157, :222-226); l2r[nL], r2l[nR] hold -1 or the partner index */
+int orbm_search_by_projection_points_fisheye(orbm_t*, const orbm_frame_t* f_l, const orbm_frame_t* f_r,
+                                             const uint8_t* blocked_l, const uint8_t* blocked_r,
+                                             const int32_t* l2r, const int32_t* r2l, const float* scale_factors,
+                                             int nq, const uint8_t* in_view, const float* px, const float* py, const float* view_cos, const int32_t* level,
+                                             const uint8_t* in_view_r, const float* pxr, const float* pyr, const float* view_cos_r, const int32_t* level_r,
+                                             const uint8_t* qdesc, const uint8_t* mp_obs, float th, float nnratio, int32_t* match_l, int32_t* match_r);
+/* M7 with F.Nleft != -1 (ORBmatcher.cc:405-426, 471-500): frame features [0,nleft) are left, the rest right */
+int orbm_search_by_bow_fisheye(orbm_t*, int nkf, const orbm_kp_t* kps_kf, const uint8_t* desc_kf, const uint8_t* kf_good,
+                               int nnk, const int32_t* nodes_k, const int32_t* start_k, const int32_t* idx_k,
+                               int nf, int nleft, const orbm_kp_t* kps_f, const uint8_t* desc_f,
+                               int nnf, const int32_t* nodes_f, const int32_t* start_f, const int32_t* idx_f,
+                               float nnratio, int check_ori, int32_t* f_match);
+
 /* M9  ORBmatcher::SearchForInitialization (ORBmatcher.cc:799-943); prev_matched_xy is updated in place */
 int orbm_search_for_initialization(orbm_t*, const orbm_frame_t* f1, const orbm_frame_t* f2, float* prev_matched_xy,
                                    int window, float nnratio, int check_ori, int32_t* matches12);

@@ -170,6 +170,30 @@ int orbref_bow_transform(const orbref_vocab_t*, const uint8_t* desc, int n, int 
 int orbref_bow_vectors(int n, const int32_t* word_id, const int32_t* node_id, const double* weight,
                        int32_t* bow_ids, double* bow_vals, int* nbow,
                        int32_t* fv_nodes, int32_t* fv_start, int32_t* fv_idx, int* nfv);
+/* ---- fisheye stereo (Nleft != -1) twins: left and right keypoints live in separate arrays / grids
+ * (mvKeys + mGrid, mvKeysRight + mGridRight), MapPoint slots are [0,Nleft) and [Nleft, Nleft+Nright) ---- */
+/* ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) with the right-camera block (ORBmatcher.cc:2615-2680).
+ * (uR, vR) = projection into the right camera.  match_l[nL] / match_r[nR] = last-frame feature index or -1. */
+int orbref_search_by_projection_frame_fisheye(const orbref_frame_t* cur_l, const orbref_frame_t* cur_r,
+                                              const uint8_t* blocked_l, const uint8_t* blocked_r, const float* scale_factors,
+                                              int nq, const uint8_t* valid, const float* u, const float* v, const float* ur, const float* vr,
+                                              const int32_t* octave, const float* angle, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                              float th, int forward, int backward, int check_ori, int32_t* match_l, int32_t* match_r);
+/* ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, ...) with the right-camera block (ORBmatcher.cc:170-236) and
+ * the mvLeftToRightMatch / mvRightToLeftMatch cross assignments (:152-157, :222-226). */
+int orbref_search_by_projection_points_fisheye(const orbref_frame_t* f_l, const orbref_frame_t* f_r,
+                                               const uint8_t* blocked_l, const uint8_t* blocked_r,
+                                               const int32_t* l2r, const int32_t* r2l, const float* scale_factors,
+                                               int nq, const uint8_t* in_view, const float* px, const float* py, const float* view_cos, const int32_t* level,
+                                               const uint8_t* in_view_r, const float* pxr, const float* pyr, const float* view_cos_r, const int32_t* level_r,
+                                               const uint8_t* qdesc, const uint8_t* mp_obs, float th, float nnratio, int32_t* match_l, int32_t* match_r);
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&) with F.Nleft != -1 (ORBmatcher.cc:405-426, 471-500): frame features
+ * [0,nleft) are left, the rest right; the right twin has its ratio test disabled (`|| true`). */
+int orbref_search_by_bow_fisheye(int nkf, const orbref_kp_t* kps_kf, const uint8_t* desc_kf, const uint8_t* kf_good,
+                         int nnk, const int32_t* nodes_k, const int32_t* start_k, const int32_t* idx_k,
+                         int nf, int nleft, const orbref_kp_t* kps_f, const uint8_t* desc_f,
+                         int nnf, const int32_t* nodes_f, const int32_t* start_f, const int32_t* idx_f,
+                         float nnratio, int check_ori, int32_t* f_match);
 /* Frame::ComputeStereoMatches (Frame.cc:1027-1276).  Pyramids are those of the two extractors' last call. */
 int orbref_stereo_matches(const orbref_t* left, const orbref_t* right,
                           int nl, const orbref_kp_t* kl, const uint8_t* dl, int nr, const orbref_kp_t* kr, const uint8_t* dr,

@@ -595,6 +595,196 @@ int orbref_search_by_sim3(const orbref_frame_t* kf1, const orbref_frame_t* kf2, 
     return nFound;
 }
 
+
+int orbref_search_by_projection_frame_fisheye(const orbref_frame_t* cur_l, const orbref_frame_t* cur_r,
+                                              const uint8_t* blocked_l_in, const uint8_t* blocked_r_in, const float* sf,
+                                              int nq, const uint8_t* valid, const float* u, const float* v, const float* ur, const float* vr,
+                                              const int32_t* octave, const float* angle, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                              float th, int bForward, int bBackward, int check_ori, int32_t* match_l, int32_t* match_r) {
+    int nmatches = 0;
+    const int Nleft = cur_l->n;
+    RotHist rh;                                                               // holds global indices (right ones offset by Nleft)
+    const float factor = HISTO_LENGTH / 360.0f;
+    std::vector<uint8_t> bl(blocked_l_in, blocked_l_in + cur_l->n), br(blocked_r_in, blocked_r_in + cur_r->n);
+    for (int i = 0; i < cur_l->n; ++i) match_l[i] = -1;
+    for (int i = 0; i < cur_r->n; ++i) match_r[i] = -1;
+    std::vector<int> vIndices2;
+    for (int i = 0; i < nq; ++i) {
+        if (!valid[i]) continue;
+        const int nLastOctave = octave[i];
+        const float radius = th * sf[nLastOctave];
+        auto area = [&](const orbref_frame_t* f, float x, float y) {
+            if (bForward) features_in_area(f, x, y, radius, nLastOctave, -1, vIndices2);
+            else if (bBackward) features_in_area(f, x, y, radius, 0, nLastOctave, vIndices2);
+            else features_in_area(f, x, y, radius, nLastOctave - 1, nLastOctave + 1, vIndices2);
+        };
+        area(cur_l, u[i], v[i]);
+        if (vIndices2.empty()) continue;                                      // :2551 -- also skips the right-camera block
+        int bestDist = 256, bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            if (bl[i2]) continue;
+            const int dist = orbref_hamming(qdesc + 32 * (size_t)i, cur_l->desc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            match_l[bestIdx2] = i;
+            if (mp_obs[i]) bl[bestIdx2] = 1;
+            nmatches++;
+            if (check_ori) rh.add(angle[i], cur_l->kps[bestIdx2].angle, factor, bestIdx2);
+        }
+        area(cur_r, ur[i], vr[i]);                                            // :2615-2627
+        bestDist = 256; bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            if (br[i2]) continue;
+            const int dist = orbref_hamming(qdesc + 32 * (size_t)i, cur_r->desc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            match_r[bestIdx2] = i;
+            if (mp_obs[i]) br[bestIdx2] = 1;
+            nmatches++;
+            if (check_ori) rh.add(angle[i], cur_r->kps[bestIdx2].angle, factor, bestIdx2 + Nleft);
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int b = 0; b < HISTO_LENGTH; ++b)
+            if (b != ind[0] && b != ind[1] && b != ind[2])
+                for (int idx : rh.bins[b]) { if (idx < Nleft) match_l[idx] = -1; else match_r[idx - Nleft] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
+int orbref_search_by_projection_points_fisheye(const orbref_frame_t* f_l, const orbref_frame_t* f_r,
+                                               const uint8_t* blocked_l_in, const uint8_t* blocked_r_in,
+                                               const int32_t* l2r, const int32_t* r2l, const float* sf,
+                                               int nq, const uint8_t* in_view, const float* px, const float* py, const float* view_cos, const int32_t* level,
+                                               const uint8_t* in_view_r, const float* pxr, const float* pyr, const float* view_cos_r, const int32_t* level_r,
+                                               const uint8_t* qdesc, const uint8_t* mp_obs, float th, float nnratio, int32_t* match_l, int32_t* match_r) {
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    std::vector<uint8_t> bl(blocked_l_in, blocked_l_in + f_l->n), br(blocked_r_in, blocked_r_in + f_r->n);
+    for (int i = 0; i < f_l->n; ++i) match_l[i] = -1;
+    for (int i = 0; i < f_r->n; ++i) match_r[i] = -1;
+    std::vector<int> vIndices;
+    for (int iMP = 0; iMP < nq; ++iMP) {
+        if (!in_view[iMP] && !in_view_r[iMP]) continue;
+        if (in_view[iMP]) {
+            const int nPredictedLevel = level[iMP];
+            float r = view_cos[iMP] > 0.998 ? 2.5f : 4.0f;
+            if (bFactor) r *= th;
+            features_in_area(f_l, px[iMP], py[iMP], r * sf[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel, vIndices);
+            if (!vIndices.empty()) {
+                int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+                for (int idx : vIndices) {
+                    if (bl[idx]) continue;
+                    const int dist = orbref_hamming(qdesc + 32 * (size_t)iMP, f_l->desc + 32 * (size_t)idx);
+                    if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = f_l->kps[idx].octave; bestIdx = idx; }
+                    else if (dist < bestDist2) { bestLevel2 = f_l->kps[idx].octave; bestDist2 = dist; }
+                }
+                if (bestDist <= TH_HIGH) {
+                    if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;          // :148-149 skips the right block too
+                    if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                        match_l[bestIdx] = iMP;
+                        if (mp_obs[iMP]) bl[bestIdx] = 1;
+                        if (l2r[bestIdx] != -1) {                                                 // :152-157
+                            match_r[l2r[bestIdx]] = iMP;
+                            if (mp_obs[iMP]) br[l2r[bestIdx]] = 1;
+                            nmatches++;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+        }
+        if (in_view_r[iMP]) {                                                                     // :170-236
+            const int nPredictedLevel = level_r[iMP];
+            if (nPredictedLevel != -1) {
+                const float r = view_cos_r[iMP] > 0.998 ? 2.5f : 4.0f;                            // no th factor here (:174)
+                features_in_area(f_r, pxr[iMP], pyr[iMP], r * sf[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel, vIndices);
+                if (vIndices.empty()) continue;
+                int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+                for (int idx : vIndices) {
+                    if (br[idx]) continue;
+                    const int dist = orbref_hamming(qdesc + 32 * (size_t)iMP, f_r->desc + 32 * (size_t)idx);
+                    if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = f_r->kps[idx].octave; bestIdx = idx; }
+                    else if (dist < bestDist2) { bestLevel2 = f_r->kps[idx].octave; bestDist2 = dist; }
+                }
+                if (bestDist <= TH_HIGH) {
+                    if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+                    if (r2l[bestIdx] != -1) {                                                     // :222-226
+                        match_l[r2l[bestIdx]] = iMP;
+                        if (mp_obs[iMP]) bl[r2l[bestIdx]] = 1;
+                        nmatches++;
+                    }
+                    match_r[bestIdx] = iMP;
+                    if (mp_obs[iMP]) br[bestIdx] = 1;
+                    nmatches++;
+                }
+            }
+        }
+    }
+    return nmatches;
+}
+
+int orbref_search_by_bow_fisheye(int nkf, const orbref_kp_t* kps_kf, const uint8_t* desc_kf, const uint8_t* kf_good,
+                         int nnk, const int32_t* nodes_k, const int32_t* start_k, const int32_t* idx_k,
+                         int nf, int nleft, const orbref_kp_t* kps_f, const uint8_t* desc_f,
+                         int nnf, const int32_t* nodes_f, const int32_t* start_f, const int32_t* idx_f,
+                         float nnratio, int check_ori, int32_t* f_match) {
+    for (int i = 0; i < nf; ++i) f_match[i] = -1;
+    int nmatches = 0;
+    RotHist rh;
+    const float factor = HISTO_LENGTH / 360.0f;
+    int a = 0, b = 0;
+    while (a < nnk && b < nnf) {
+        if (nodes_k[a] == nodes_f[b]) {
+            for (int iKF = start_k[a]; iKF < start_k[a + 1]; ++iKF) {
+                const int realIdxKF = idx_k[iKF];
+                if (!kf_good[realIdxKF]) continue;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256, bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
+                for (int iF = start_f[b]; iF < start_f[b + 1]; ++iF) {
+                    const int realIdxF = idx_f[iF];
+                    if (f_match[realIdxF] >= 0) continue;
+                    const int dist = orbref_hamming(desc_kf + 32 * (size_t)realIdxKF, desc_f + 32 * (size_t)realIdxF);
+                    if (realIdxF < nleft && dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                    else if (realIdxF < nleft && dist < bestDist2) bestDist2 = dist;
+                    if (realIdxF >= nleft && dist < bestDist1R) { bestDist2R = bestDist1R; bestDist1R = dist; bestIdxFR = realIdxF; }
+                    else if (realIdxF >= nleft && dist < bestDist2R) bestDist2R = dist;
+                }
+                if (bestDist1 <= TH_LOW) {
+                    if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                        f_match[bestIdxF] = realIdxKF;
+                        if (check_ori) rh.add(kps_kf[realIdxKF].angle, kps_f[bestIdxF].angle, factor, bestIdxF);
+                        nmatches++;
+                    }
+                    if (bestDist1R <= TH_LOW) {                                                   // nested, ratio test disabled (:471-473)
+                        f_match[bestIdxFR] = realIdxKF;
+                        if (check_ori) rh.add(kps_kf[realIdxKF].angle, kps_f[bestIdxFR].angle, factor, bestIdxFR);
+                        nmatches++;
+                    }
+                }
+            }
+            ++a; ++b;
+        } else if (nodes_k[a] < nodes_f[b]) {
+            a = (int)(std::lower_bound(nodes_k, nodes_k + nnk, nodes_f[b]) - nodes_k);
+        } else {
+            b = (int)(std::lower_bound(nodes_f, nodes_f + nnf, nodes_k[a]) - nodes_f);
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int bb = 0; bb < HISTO_LENGTH; ++bb) {
+            if (bb == ind[0] || bb == ind[1] || bb == ind[2]) continue;
+            for (int i : rh.bins[bb]) { f_match[i] = -1; nmatches--; }
+        }
+    }
+    (void)nkf;
+    return nmatches;
+}
+
 int orbref_stereo_matches(const orbref_t* left, const orbref_t* right,
                           int N, const orbref_kp_t* kl, const uint8_t* dl, int Nr, const orbref_kp_t* kr, const uint8_t* dr,
                           float mb, float mbf, float* mvuRight, float* mvDepth) {

@@ -364,6 +364,9 @@ def _bind_search(L, prefix):
     g("search_for_triangulation_legacy").argtypes = g("search_for_triangulation").argtypes
     g("search_by_projection_kf").argtypes = h + [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp]
     g("search_by_projection_sim3").argtypes = h + [vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, cf, vp]
+    g("search_by_projection_frame_fisheye").argtypes = h + [vp, vp, vp, vp, vp, ci] + [vp] * 9 + [cf, ci, ci, ci, vp, vp]
+    g("search_by_projection_points_fisheye").argtypes = h + [vp] * 7 + [ci] + [vp] * 12 + [cf, cf, vp, vp]
+    g("search_by_bow_fisheye").argtypes = h + [ci, vp, vp, vp, ci, vp, vp, vp, ci, ci, vp, vp, ci, vp, vp, vp, cf, ci, vp]
     g("search_by_sim3").argtypes = h + [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, vp]
     g("fuse").argtypes = h + [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, vp]
     g("search_by_bow_kf").argtypes = h + [ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, cf, ci, vp]
@@ -464,6 +467,42 @@ class _SearchMixin:
                        int(th), float(ratio_hamming), _p(match))
         return n, match
 
+    def SearchByProjectionFrameFisheye(self, cur_l, cur_r, blocked_l, blocked_r, scale_factors, valid, u, v, ur, vr, octave, angle,
+                                       qdesc, mp_obs, th, forward=False, backward=False, check_ori=True):
+        ml = np.full(cur_l.n, -1, np.int32); mr = np.full(cur_r.n, -1, np.int32)
+        cl, cr = cur_l.cstruct(), cur_r.cstruct()
+        arr = [np.ascontiguousarray(a, t) for a, t in ((blocked_l, np.uint8), (blocked_r, np.uint8), (scale_factors, np.float32),
+               (valid, np.uint8), (u, np.float32), (v, np.float32), (ur, np.float32), (vr, np.float32), (octave, np.int32),
+               (angle, np.float32), (qdesc, np.uint8), (mp_obs, np.uint8))]
+        n = self._call("search_by_projection_frame_fisheye", C.byref(cl), C.byref(cr), _p(arr[0]), _p(arr[1]), _p(arr[2]), len(arr[3]),
+                       *[_p(a) for a in arr[3:]], float(th), int(forward), int(backward), int(check_ori), _p(ml), _p(mr))
+        return n, ml, mr
+
+    def SearchByProjectionPointsFisheye(self, f_l, f_r, blocked_l, blocked_r, l2r, r2l, scale_factors, left, right, qdesc, mp_obs, th, nnratio):
+        """left / right: dicts with in_view, px, py, view_cos, level for the two cameras."""
+        ml = np.full(f_l.n, -1, np.int32); mr = np.full(f_r.n, -1, np.int32)
+        cl, cr = f_l.cstruct(), f_r.cstruct()
+        def pack(q):
+            return [np.ascontiguousarray(q["in_view"], np.uint8), np.ascontiguousarray(q["px"], np.float32), np.ascontiguousarray(q["py"], np.float32),
+                    np.ascontiguousarray(q["view_cos"], np.float32), np.ascontiguousarray(q["level"], np.int32)]
+        a = [np.ascontiguousarray(blocked_l, np.uint8), np.ascontiguousarray(blocked_r, np.uint8), np.ascontiguousarray(l2r, np.int32),
+             np.ascontiguousarray(r2l, np.int32), np.ascontiguousarray(scale_factors, np.float32)]
+        L_, R_ = pack(left), pack(right)
+        qd = np.ascontiguousarray(qdesc, np.uint8); ob = np.ascontiguousarray(mp_obs, np.uint8)
+        n = self._call("search_by_projection_points_fisheye", C.byref(cl), C.byref(cr), *[_p(x) for x in a], len(L_[0]),
+                       *[_p(x) for x in L_], *[_p(x) for x in R_], _p(qd), _p(ob), float(th), float(nnratio), _p(ml), _p(mr))
+        return n, ml, mr
+
+    def SearchByBoWFisheye(self, kkf, dkf, kf_good, fvk, kf_, df, nleft, fvf, nnratio, check_ori=True):
+        fm = np.full(len(kf_), -1, np.int32)
+        kkf = np.ascontiguousarray(kkf); kf_ = np.ascontiguousarray(kf_)
+        dkf = np.ascontiguousarray(dkf, np.uint8); df = np.ascontiguousarray(df, np.uint8)
+        good = np.ascontiguousarray(kf_good, np.uint8)
+        n = self._call("search_by_bow_fisheye", len(kkf), _p(kkf), _p(dkf), _p(good), len(fvk[0]), _p(fvk[0]), _p(fvk[1]), _p(fvk[2]),
+                       len(kf_), int(nleft), _p(kf_), _p(df), len(fvf[0]), _p(fvf[0]), _p(fvf[1]), _p(fvf[2]),
+                       float(nnratio), int(check_ori), _p(fm))
+        return n, fm
+
     def SearchBySim3(self, kf1, kf2, sf1, sf2, q1, q2, th):
         """q1 / q2: dicts with valid, u, v, level, qdesc for the KF1->KF2 and KF2->KF1 projections."""
         m12 = np.full(kf1.n, -1, np.int32)
@@ -530,7 +569,8 @@ def _install_search():
     L.orbm_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     for name in ("grid_build", "SearchByProjectionFrame", "SearchByProjectionPoints", "SearchForInitialization",
-                 "SearchForTriangulation", "SearchByBoW", "SearchByProjectionKF", "SearchByBoWKF", "SearchByProjectionSim3", "Fuse", "SearchBySim3", "_call"):
+                 "SearchForTriangulation", "SearchByBoW", "SearchByProjectionKF", "SearchByBoWKF", "SearchByProjectionSim3", "Fuse", "SearchBySim3", "SearchByProjectionFrameFisheye",
+                 "SearchByProjectionPointsFisheye", "SearchByBoWFisheye", "_call"):
         setattr(ORBmatcher, name, getattr(_SearchMixin, name))
     ORBmatcher._prefix = "orbm_"
 
@@ -575,7 +615,8 @@ EXPORTS += ["orbm_grid_build", "orbm_window_candidates", "orbm_search_by_project
             "orbm_search_for_initialization", "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_stereo_matches",
             "orbm_search_by_projection_kf", "orbm_search_by_bow_kf", "orbm_search_for_triangulation_legacy",
             "orbm_search_by_projection_sim3", "orbm_fuse", "orbm_search_by_sim3",
-            "orbm_grid_build_batch_async", "orbm_track_window_batch_async",
+            "orbm_grid_build_batch_async", "orbm_track_window_batch_async", "orbm_search_by_projection_frame_fisheye",
+            "orbm_search_by_projection_points_fisheye", "orbm_search_by_bow_fisheye",
             "orbm_vocab_load_text", "orbm_vocab_create", "orbm_vocab_destroy", "orbm_vocab_info", "orbm_bow_transform", "orbm_bow_vectors"]
 _orig_lib = lib
 _search_ready = False

@@ -864,6 +864,202 @@ int orbm_bow_vectors(int n, const int32_t* word_id, const int32_t* node_id, cons
     return ORBM_OK;
 }
 
+int orbm_search_by_projection_frame_fisheye(orbm_t* m, const orbm_frame_t* cur_l, const orbm_frame_t* cur_r,
+                                            const uint8_t* blocked_l_in, const uint8_t* blocked_r_in, const float* sf,
+                                            int nq, const uint8_t* valid, const float* u, const float* v, const float* ur, const float* vr,
+                                            const int32_t* octave, const float* angle, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                            float th, int bForward, int bBackward, int check_ori, int32_t* match_l, int32_t* match_r) {
+    if (!m || !cur_l || !cur_r || nq < 0) return ORBM_E_INVALID;
+    std::vector<float> qr(nq);
+    std::vector<int> minl(nq), maxl(nq);
+    for (int i = 0; i < nq; ++i) {
+        if (!valid[i]) { qr[i] = -1.f; minl[i] = 0; maxl[i] = -1; continue; }
+        const int o = octave[i];
+        qr[i] = th * sf[o];
+        if (bForward) { minl[i] = o; maxl[i] = -1; } else if (bBackward) { minl[i] = 0; maxl[i] = o; } else { minl[i] = o - 1; maxl[i] = o + 1; }
+    }
+    orbm_frame_t fl = *cur_l, fr = *cur_r; fl.uright = nullptr; fr.uright = nullptr;     // no stereo gate when Nleft != -1 (:2569)
+    const int capL = std::max(1, std::min(fl.n, 2048)), capR = std::max(1, std::min(fr.n, 2048));
+    std::vector<int> cntL, idxL, distL, cntR, idxR, distR;
+    int rc = window_pass(m, &fl, nq, u, v, qr.data(), minl.data(), maxl.data(), nullptr, nullptr, qdesc, capL, cntL, idxL, distL);
+    if (rc) return rc;
+    rc = window_pass(m, &fr, nq, ur, vr, qr.data(), minl.data(), maxl.data(), nullptr, nullptr, qdesc, capR, cntR, idxR, distR);
+    if (rc) return rc;
+    int nmatches = 0;
+    const int Nleft = fl.n;
+    RotHist rh;
+    const float factor = ORBM_HISTO_LENGTH / 360.0f;
+    std::vector<uint8_t> bl(blocked_l_in, blocked_l_in + fl.n), br(blocked_r_in, blocked_r_in + fr.n);
+    for (int i = 0; i < fl.n; ++i) match_l[i] = -1;
+    for (int i = 0; i < fr.n; ++i) match_r[i] = -1;
+    for (int i = 0; i < nq; ++i) {
+        if (!valid[i] || cntL[i] == 0) continue;                            // an empty left window skips the right block too (:2551)
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < cntL[i]; ++c) {
+            const int i2 = idxL[(size_t)i * capL + c];
+            if (bl[i2]) continue;
+            const int d = distL[(size_t)i * capL + c];
+            if (d < bestDist) { bestDist = d; bestIdx2 = i2; }
+        }
+        if (bestDist <= ORBM_TH_HIGH) {
+            match_l[bestIdx2] = i;
+            if (mp_obs[i]) bl[bestIdx2] = 1;
+            nmatches++;
+            if (check_ori) rh.add(angle[i], fl.kps[bestIdx2].angle, factor, bestIdx2);
+        }
+        bestDist = 256; bestIdx2 = -1;
+        for (int c = 0; c < cntR[i]; ++c) {
+            const int i2 = idxR[(size_t)i * capR + c];
+            if (br[i2]) continue;
+            const int d = distR[(size_t)i * capR + c];
+            if (d < bestDist) { bestDist = d; bestIdx2 = i2; }
+        }
+        if (bestDist <= ORBM_TH_HIGH) {
+            match_r[bestIdx2] = i;
+            if (mp_obs[i]) br[bestIdx2] = 1;
+            nmatches++;
+            if (check_ori) rh.add(angle[i], fr.kps[bestIdx2].angle, factor, bestIdx2 + Nleft);
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int b = 0; b < ORBM_HISTO_LENGTH; ++b)
+            if (b != ind[0] && b != ind[1] && b != ind[2])
+                for (int k : rh.bins[b]) { if (k < Nleft) match_l[k] = -1; else match_r[k - Nleft] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
+int orbm_search_by_projection_points_fisheye(orbm_t* m, const orbm_frame_t* f_l, const orbm_frame_t* f_r,
+                                             const uint8_t* blocked_l_in, const uint8_t* blocked_r_in,
+                                             const int32_t* l2r, const int32_t* r2l, const float* sf,
+                                             int nq, const uint8_t* in_view, const float* px, const float* py, const float* view_cos, const int32_t* level,
+                                             const uint8_t* in_view_r, const float* pxr, const float* pyr, const float* view_cos_r, const int32_t* level_r,
+                                             const uint8_t* qdesc, const uint8_t* mp_obs, float th, float nnratio, int32_t* match_l, int32_t* match_r) {
+    if (!m || !f_l || !f_r || nq < 0) return ORBM_E_INVALID;
+    const bool bFactor = th != 1.0;
+    std::vector<float> qrl(nq), qrr(nq);
+    std::vector<int> minL(nq), maxL(nq), minR(nq), maxR(nq);
+    for (int i = 0; i < nq; ++i) {
+        if (!in_view[i]) { qrl[i] = -1.f; minL[i] = 0; maxL[i] = -1; }
+        else {
+            float r = view_cos[i] > 0.998 ? 2.5f : 4.0f;
+            if (bFactor) r *= th;
+            qrl[i] = r * sf[level[i]]; minL[i] = level[i] - 1; maxL[i] = level[i];
+        }
+        if (!in_view_r[i] || level_r[i] == -1) { qrr[i] = -1.f; minR[i] = 0; maxR[i] = -1; }
+        else {
+            const float r = view_cos_r[i] > 0.998 ? 2.5f : 4.0f;             // the right block applies no th factor (:174)
+            qrr[i] = r * sf[level_r[i]]; minR[i] = level_r[i] - 1; maxR[i] = level_r[i];
+        }
+    }
+    orbm_frame_t fl = *f_l, fr = *f_r; fl.uright = nullptr; fr.uright = nullptr;
+    const int capL = std::max(1, std::min(fl.n, 2048)), capR = std::max(1, std::min(fr.n, 2048));
+    std::vector<int> cntL, idxL, distL, cntR, idxR, distR;
+    int rc = window_pass(m, &fl, nq, px, py, qrl.data(), minL.data(), maxL.data(), nullptr, nullptr, qdesc, capL, cntL, idxL, distL);
+    if (rc) return rc;
+    rc = window_pass(m, &fr, nq, pxr, pyr, qrr.data(), minR.data(), maxR.data(), nullptr, nullptr, qdesc, capR, cntR, idxR, distR);
+    if (rc) return rc;
+    int nmatches = 0;
+    std::vector<uint8_t> bl(blocked_l_in, blocked_l_in + fl.n), br(blocked_r_in, blocked_r_in + fr.n);
+    for (int i = 0; i < fl.n; ++i) match_l[i] = -1;
+    for (int i = 0; i < fr.n; ++i) match_r[i] = -1;
+    for (int iMP = 0; iMP < nq; ++iMP) {
+        if (!in_view[iMP] && !in_view_r[iMP]) continue;
+        if (in_view[iMP] && cntL[iMP] > 0) {
+            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+            for (int c = 0; c < cntL[iMP]; ++c) {
+                const int k = idxL[(size_t)iMP * capL + c];
+                if (bl[k]) continue;
+                const int d = distL[(size_t)iMP * capL + c];
+                if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = fl.kps[k].octave; bestIdx = k; }
+                else if (d < bestDist2) { bestLevel2 = fl.kps[k].octave; bestDist2 = d; }
+            }
+            if (bestDist <= ORBM_TH_HIGH) {
+                if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;          // :148-149 (skips the right block)
+                if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                    match_l[bestIdx] = iMP;
+                    if (mp_obs[iMP]) bl[bestIdx] = 1;
+                    if (l2r[bestIdx] != -1) { match_r[l2r[bestIdx]] = iMP; if (mp_obs[iMP]) br[l2r[bestIdx]] = 1; nmatches++; }
+                    nmatches++;
+                }
+            }
+        }
+        if (in_view_r[iMP] && level_r[iMP] != -1) {
+            if (cntR[iMP] == 0) continue;
+            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+            for (int c = 0; c < cntR[iMP]; ++c) {
+                const int k = idxR[(size_t)iMP * capR + c];
+                if (br[k]) continue;
+                const int d = distR[(size_t)iMP * capR + c];
+                if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = fr.kps[k].octave; bestIdx = k; }
+                else if (d < bestDist2) { bestLevel2 = fr.kps[k].octave; bestDist2 = d; }
+            }
+            if (bestDist <= ORBM_TH_HIGH) {
+                if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+                if (r2l[bestIdx] != -1) { match_l[r2l[bestIdx]] = iMP; if (mp_obs[iMP]) bl[r2l[bestIdx]] = 1; nmatches++; }
+                match_r[bestIdx] = iMP;
+                if (mp_obs[iMP]) br[bestIdx] = 1;
+                nmatches++;
+            }
+        }
+    }
+    return nmatches;
+}
+
+int orbm_search_by_bow_fisheye(orbm_t* m, int nkf, const orbm_kp_t* kps_kf, const uint8_t* desc_kf, const uint8_t* kf_good,
+                               int nnk, const int32_t* nodes_k, const int32_t* start_k, const int32_t* idx_k,
+                               int nf, int nleft, const orbm_kp_t* kps_f, const uint8_t* desc_f,
+                               int nnf, const int32_t* nodes_f, const int32_t* start_f, const int32_t* idx_f,
+                               float nnratio, int check_ori, int32_t* f_match) {
+    if (!m || nkf < 0 || nf < 0) return ORBM_E_INVALID;
+    JoinJobs J;
+    join_nodes(nnk, nodes_k, start_k, idx_k, nnf, nodes_f, start_f, J);
+    std::vector<int> dist;
+    int rc = bucket_pass(m, desc_kf, nkf, desc_f, nf, idx_f, start_f[nnf], J, dist);
+    if (rc) return rc;
+    for (int i = 0; i < nf; ++i) f_match[i] = -1;
+    int nmatches = 0;
+    RotHist rh;
+    const float factor = ORBM_HISTO_LENGTH / 360.0f;
+    for (size_t j = 0; j < J.q.size(); ++j) {
+        const int iKF = J.q[j];
+        if (!kf_good[iKF]) continue;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256, bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
+        for (int c = 0; c < J.len[j]; ++c) {
+            const int iF = idx_f[J.l2[j] + c];
+            if (f_match[iF] >= 0) continue;
+            const int d = dist[J.off[j] + c];
+            if (iF < nleft && d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdxF = iF; }
+            else if (iF < nleft && d < bestDist2) bestDist2 = d;
+            if (iF >= nleft && d < bestDist1R) { bestDist2R = bestDist1R; bestDist1R = d; bestIdxFR = iF; }
+            else if (iF >= nleft && d < bestDist2R) bestDist2R = d;
+        }
+        if (bestDist1 <= ORBM_TH_LOW) {
+            if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                f_match[bestIdxF] = iKF;
+                if (check_ori) rh.add(kps_kf[iKF].angle, kps_f[bestIdxF].angle, factor, bestIdxF);
+                nmatches++;
+            }
+            if (bestDist1R <= ORBM_TH_LOW) {                                 // nested; ratio test disabled by `|| true` (:471-473)
+                f_match[bestIdxFR] = iKF;
+                if (check_ori) rh.add(kps_kf[iKF].angle, kps_f[bestIdxFR].angle, factor, bestIdxFR);
+                nmatches++;
+            }
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int b = 0; b < ORBM_HISTO_LENGTH; ++b) {
+            if (b == ind[0] || b == ind[1] || b == ind[2]) continue;
+            for (int i : rh.bins[b]) { f_match[i] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 int orbm_search_by_bow_kf(orbm_t* m, int n1, const orbm_kp_t* kps1, const uint8_t* desc1, const uint8_t* good1,
                           int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
                           int n2, const orbm_kp_t* kps2, const uint8_t* desc2, const uint8_t* good2,

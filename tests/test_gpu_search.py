@@ -230,6 +230,57 @@ def test_search_by_sim3(pkg, scene):
     assert out[0][0] > 20
 
 
+@pytest.mark.parametrize("th,fwd,bwd,ori", [(15, 0, 0, True), (7, 1, 0, True), (7, 0, 1, False)])
+def test_search_by_projection_frame_fisheye(pkg, scene, th, fwd, bwd, ori):
+    # fisheye stereo (TUM-VI, BASELINE config C4): the current frame has separate left / right keypoint sets and grids
+    rng = np.random.default_rng(900 + th + fwd)
+    kl, kr, dl, dr = scene["kl"], scene["kr"], scene["dl"], scene["dr"]
+    n = len(kl)
+    args = dict(blocked_l=rng.random(len(kl)) < 0.05, blocked_r=rng.random(len(kr)) < 0.05, scale_factors=scene["sf"],
+                valid=rng.random(n) < 0.85, u=(kl["x"] + rng.normal(0, 3, n)).astype(np.float32), v=(kl["y"] + rng.normal(0, 1, n)).astype(np.float32),
+                ur=(kl["x"] - 20 + rng.normal(0, 3, n)).astype(np.float32), vr=(kl["y"] + rng.normal(0, 1, n)).astype(np.float32),
+                octave=kl["octave"], angle=kl["angle"], qdesc=dl, mp_obs=rng.random(n) < 0.9, th=th, forward=bool(fwd), backward=bool(bwd), check_ori=ori)
+    out = []
+    for b in (scene["m"], scene["OM"]):
+        vl = pkg.FrameView(kl, dl, 752, 480, backend=b); vr_ = pkg.FrameView(kr, dr, 752, 480, backend=b)
+        out.append(b.SearchByProjectionFrameFisheye(vl, vr_, **args))
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert (out[0][1] >= 0).sum() > 50 and (out[0][2] >= 0).sum() > 20
+
+
+@pytest.mark.parametrize("th,nnratio", [(1.0, 0.8), (3.0, 0.9)])
+def test_search_by_projection_points_fisheye(pkg, scene, th, nnratio):
+    rng = np.random.default_rng(950 + int(th))
+    kl, kr, dl, dr = scene["kl"], scene["kr"], scene["dl"], scene["dr"]
+    n = len(kl)
+    l2r = np.where(rng.random(len(kl)) < 0.3, rng.integers(0, len(kr), len(kl)), -1).astype(np.int32)
+    r2l = np.where(rng.random(len(kr)) < 0.3, rng.integers(0, len(kl), len(kr)), -1).astype(np.int32)
+    left = dict(in_view=rng.random(n) < 0.8, px=(kl["x"] + rng.normal(0, 2, n)).astype(np.float32), py=(kl["y"] + rng.normal(0, 1, n)).astype(np.float32),
+                view_cos=rng.uniform(0.99, 1.0, n), level=kl["octave"])
+    right = dict(in_view=rng.random(n) < 0.6, px=(kl["x"] - 20 + rng.normal(0, 2, n)).astype(np.float32), py=(kl["y"] + rng.normal(0, 1, n)).astype(np.float32),
+                 view_cos=rng.uniform(0.99, 1.0, n), level=np.where(rng.random(n) < 0.1, -1, kl["octave"]))
+    args = dict(blocked_l=rng.random(len(kl)) < 0.05, blocked_r=rng.random(len(kr)) < 0.05, l2r=l2r, r2l=r2l, scale_factors=scene["sf"],
+                left=left, right=right, qdesc=dl, mp_obs=rng.random(n) < 0.9, th=th, nnratio=nnratio)
+    out = []
+    for b in (scene["m"], scene["OM"]):
+        vl = pkg.FrameView(kl, dl, 752, 480, backend=b); vr_ = pkg.FrameView(kr, dr, 752, 480, backend=b)
+        out.append(b.SearchByProjectionPointsFisheye(vl, vr_, **args))
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert out[0][0] > 50
+
+
+@pytest.mark.parametrize("bits,ori", [(5, True), (7, False)])
+def test_search_by_bow_fisheye(pkg, scene, bits, ori):
+    rng = np.random.default_rng(bits + 700)
+    kl, kr, dl, dr = scene["kl"], scene["kr"], scene["dl"], scene["dr"]
+    # the frame's descriptor block is vconcat(left, right) (Frame.cc:1428); the keyframe is the left set here
+    kf = np.concatenate([kr, kl[::-1]]); df = np.concatenate([dr, dl[::-1]])
+    args = dict(kkf=kl, dkf=dl, kf_good=rng.random(len(kl)) < 0.8, fvk=_fv(pkg, dl, bits), kf_=kf, df=df, nleft=len(kr), fvf=_fv(pkg, df, bits),
+                nnratio=0.7, check_ori=ori)
+    a = scene["m"].SearchByBoWFisheye(**args); b = scene["OM"].SearchByBoWFisheye(**args)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[0] > 10
+
+
 def test_compute_stereo_matches(pkg, scene):
     # EuRoC stereo: bf = 47.906, fx = 435.2 -> mb = bf/fx (Examples/Stereo/EuRoC.yaml:9,28)
     mbf = 47.90639384423901; mb = mbf / 435.2046959714599
