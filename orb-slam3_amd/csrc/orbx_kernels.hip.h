@@ -1271,11 +1271,14 @@ __global__ __launch_bounds__(256) void k_orient_desc(Geom g, const u8* const* l0
 //    descriptor bytes 2q and 2q+1 already in LSB-first bit order (bit s of the group's 16-bit field).
 //    The 512 pattern points sit in LDS as floats (staged once per workgroup).
 // ------------------------------------------------------------------------------------------------
+#define OD_PPITCH 40
+#define OD_PATCH (37 * OD_PPITCH)
 __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
                                                       const u8* blr, const KpWork* __restrict__ work,
                                                       const int* __restrict__ nOut, KpOut* kps, u8* desc,
                                                       const int8_t* __restrict__ pattern, Umax um) {
     __shared__ float4 spat[256];                               // (x0, y0, x1, y1) per pair
+    __shared__ __attribute__((aligned(16))) u8 bpatch[16 * OD_PATCH];   // blurred 37 x 40-byte patch of each of the 16 keypoints
     const int tid = threadIdx.x;
     {
         const int raw = ((const int*)pattern)[tid];
@@ -1294,13 +1297,15 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
     // ---- orientation: all 64 lanes work on one keypoint's 31 x 9 dwords at a time; the 4 x 5 loads of the whole
     // wave are issued before any arithmetic (one memory round trip instead of four)
     int m10s[4] = {0, 0, 0, 0}, m01s[4] = {0, 0, 0, 0};
-    u32 dq[4][5];
+    u32 dq[4][5], bq[4][6];
     int cxs[4], xals[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         cxs[k] = 0; xals[k] = 0;
 #pragma unroll
         for (int it = 0; it < 5; ++it) dq[k][it] = 0;
+#pragma unroll
+        for (int it = 0; it < 6; ++it) bq[k][it] = 0;
         if (base + k < n) {                                     // wave-uniform
             const int level = __builtin_amdgcn_readfirstlane(__shfl((int)w.level, 16 * k));
             const int cx = __builtin_amdgcn_readfirstlane(__shfl((int)w.x, 16 * k));
@@ -1316,8 +1321,32 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
                 const int j = idx - r * 9;
                 if (r < 31) dq[k][it] = gload32(im + (size_t)(cy + r - 15) * sp + xal + 4 * j);
             }
+            // blurred patch: rows cy-18..cy+18, 10 aligned dwords from (cx-18)&~3
+            const LevelDesc& Lk = g.lv[level];
+            const u8* bl = blr + (size_t)frame * g.pyrFrameBytes + Lk.off;
+            const int xalb = (cx - 18) & ~3;
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int idx = it * 64 + lane;
+                const int r = (idx * 205) >> 11;                // idx / 10 for idx < 384
+                const int j = idx - r * 10;
+                if (r < 37) bq[k][it] = gload32(bl + (size_t)(cy + r - 18) * Lk.pitch + xalb + 4 * j);
+            }
         }
     }
+    {   // park the blurred patches in LDS (each wave owns 4 patches; same-wave LDS traffic needs no barrier)
+        u8* mine = bpatch + (threadIdx.x >> 6) * 4 * OD_PATCH;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int idx = it * 64 + lane;
+                if (idx < 370) *(u32*)(mine + k * OD_PATCH + idx * 4) = bq[k][it];
+            }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int bxoff = w.x - ((w.x - 18) & ~3);                  // column of the keypoint inside its patch
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (base + k < n) {
@@ -1355,18 +1384,17 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ar = angle * factorPI;
     const float a = (float)cos((double)ar), b = (float)sin((double)ar);
-    // ---- descriptor: 16 pairs per lane on the blurred level of the lane's own keypoint
-    const LevelDesc& L = g.lv[w.level];
-    const int bp = L.pitch;
-    const u8* bc = blr + (size_t)frame * g.pyrFrameBytes + L.off + (size_t)w.y * bp + w.x;
+    // ---- descriptor: 16 pairs per lane, sampled from the LDS copy of the keypoint's 37-row blurred patch (the patch
+    // rows were requested together with the orientation rows: one global round trip per wave instead of two)
+    const u8* pc = bpatch + ((threadIdx.x >> 6) * 4 + sub) * OD_PATCH + 18 * OD_PPITCH + bxoff;
     u8 t0[16], t1[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const float4 pt = spat[q * 16 + sl];
-        const int o0 = __float2int_rn(pt.x * b + pt.y * a) * bp + __float2int_rn(pt.x * a - pt.y * b);
-        const int o1 = __float2int_rn(pt.z * b + pt.w * a) * bp + __float2int_rn(pt.z * a - pt.w * b);
-        t0[q] = valid ? gload8(bc + o0) : (u8)0;
-        t1[q] = valid ? gload8(bc + o1) : (u8)0;
+        const int o0 = __float2int_rn(pt.x * b + pt.y * a) * OD_PPITCH + __float2int_rn(pt.x * a - pt.y * b);
+        const int o1 = __float2int_rn(pt.z * b + pt.w * a) * OD_PPITCH + __float2int_rn(pt.z * a - pt.w * b);
+        t0[q] = valid ? pc[o0] : (u8)0;
+        t1[q] = valid ? pc[o1] : (u8)0;
     }
     u32 myword = 0;
 #pragma unroll
