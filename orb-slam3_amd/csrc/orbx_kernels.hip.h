@@ -398,13 +398,16 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
             const int lc = lane - lr * ncol;
             const bool lact = lr < rpi;
             const int tx8 = (c80 + lc) << 3;
+            // survivor flags live in a sparse layout: pixel k of the lane's 8 at bit 4k+3 (that is where two v_perm drop
+            // the sign bits; popcount and ctz do not care about the spacing, and ascending bits are ascending x)
             u32 colmask = 0;
 #pragma unroll
-            for (int bb = 0; bb < 8; ++bb) if (tx8 + bb >= cx0 && tx8 + bb < cx1) colmask |= 1u << bb;
+            for (int bb = 0; bb < 8; ++bb)
+                if (tx8 + bb >= cx0 && tx8 + bb < cx1) colmask |= 8u << (4 * bb);
             for (int pass = 0; pass < 2; ++pass) {
                 const int t = pass == 0 ? g.iniTh : g.minTh;
                 if (pass == 1 && g.minTh >= g.iniTh) break;               // a higher retry threshold cannot add corners
-                const u32 tt = (u32)t * 0x00010001u;
+                const us2 t2 = as_us2((u32)t * 0x00010001u);
                 // ---- quick reject + compaction: 8 px per lane, lane -> fixed 8-px column (no per-iteration index math)
                 int n1 = 0;
 #ifdef F3_ABL_NOQUICK
@@ -420,39 +423,49 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
                         const uint2 Bq = *(const uint2*)rowc;
                         const u32 A = *(const u32*)(rowc - 4), Cw = *(const u32*)(rowc + 8);
                         const uint2 Uq = *(const uint2*)(rowc - 3 * Pb), Dq = *(const uint2*)(rowc + 3 * Pb);
-                        const u32 Bv[2] = {Bq.x, Bq.y}, Uv[2] = {Uq.x, Uq.y}, Dv[2] = {Dq.x, Dq.y};
-                        const u32 Lv[2] = {__builtin_amdgcn_alignbyte(Bq.x, A, 1), __builtin_amdgcn_alignbyte(Bq.y, Bq.x, 1)};
-                        const u32 Rv[2] = {__builtin_amdgcn_alignbyte(Bq.y, Bq.x, 3), __builtin_amdgcn_alignbyte(Cw, Bq.y, 3)};
+                        // even / odd bytes of every word as 16-bit pairs: e* = pixels (0,2) of the word, o* = pixels (1,3)
+                        const u32 SE = 0x0c020c00u, SO = 0x0c030c01u;
+#define F3_E(w) as_us2(__builtin_amdgcn_perm(0, (w), SE))
+#define F3_O(w) as_us2(__builtin_amdgcn_perm(0, (w), SO))
+#define F3_AL(hi, lo) as_us2(__builtin_amdgcn_alignbyte(as_u32(hi), as_u32(lo), 2))   /* (lo.hi16, hi.lo16) */
+                        const us2 eA = F3_E(A), oA = F3_O(A), eB0 = F3_E(Bq.x), oB0 = F3_O(Bq.x), eB1 = F3_E(Bq.y),
+                                  oB1 = F3_O(Bq.y), eC = F3_E(Cw), oC = F3_O(Cw);
+                        // pixel groups of the lane's 8: G0 = (0,2) G1 = (1,3) G2 = (4,6) G3 = (5,7); left = x-3, right = x+3
+                        const us2 vv[4] = {eB0, oB0, eB1, oB1};
+                        const us2 uu[4] = {F3_E(Uq.x), F3_O(Uq.x), F3_E(Uq.y), F3_O(Uq.y)};
+                        const us2 dd[4] = {F3_E(Dq.x), F3_O(Dq.x), F3_E(Dq.y), F3_O(Dq.y)};
+                        const us2 ll[4] = {oA, F3_AL(eB0, eA), oB0, F3_AL(eB1, eB0)};
+                        const us2 rr4[4] = {F3_AL(oB1, oB0), eB1, F3_AL(oC, oB1), eC};
+#undef F3_E
+#undef F3_O
+#undef F3_AL
+                        u32 sg[4];
 #pragma unroll
-                        for (int w4 = 0; w4 < 2; ++w4)
-#pragma unroll
-                            for (int hlf = 0; hlf < 2; ++hlf) {
-                                const u32 sel = hlf ? 0x0c030c02u : 0x0c010c00u;
-                                const us2 v = as_us2(__builtin_amdgcn_perm(0, Bv[w4], sel)), up = as_us2(__builtin_amdgcn_perm(0, Uv[w4], sel)),
-                                          dn = as_us2(__builtin_amdgcn_perm(0, Dv[w4], sel)), lf = as_us2(__builtin_amdgcn_perm(0, Lv[w4], sel)),
-                                          rt = as_us2(__builtin_amdgcn_perm(0, Rv[w4], sel));
-                                const us2 t2 = as_us2(tt);
-                                const us2 X = pkmax(pkmin(up, dn), pkmin(lf, rt));
-                                const us2 Y = pkmin(pkmax(up, dn), pkmax(lf, rt));
-                                const u32 rr = as_u32((X - (v - t2)) | ((v + t2) - Y));
-                                m |= (((rr >> 15) & 1u) | ((rr >> 30) & 2u)) << (4 * w4 + 2 * hlf);
-                            }
-                        m &= colmask;
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const us2 X = pkmax(pkmin(uu[gq], dd[gq]), pkmin(ll[gq], rr4[gq]));
+                            const us2 Y = pkmin(pkmax(uu[gq], dd[gq]), pkmax(ll[gq], rr4[gq]));
+                            sg[gq] = as_u32((X - (vv[gq] - t2)) | ((vv[gq] + t2) - Y));   // sign bit of a half = survivor
+                        }
+                        const u32 Me = __builtin_amdgcn_perm(sg[2], sg[0], 0x07050301u);   // high bytes of px 0,2,4,6
+                        const u32 Mo = __builtin_amdgcn_perm(sg[3], sg[1], 0x07050301u);   // px 1,3,5,7
+                        m = (((Me >> 4) & 0x08080808u) | (Mo & 0x80808080u)) & colmask;
                     }
-                    // wave prefix of popcount(m) (0..8) from 4 ballots, then each lane appends its own survivors
+                    // wave-inclusive prefix of popcount(m) (0..8) by a DPP scan, then each lane appends its own survivors
                     const int c = __popc(m);
-                    int pre = 0, tot = 0;
-#pragma unroll
-                    for (int bb = 0; bb < 4; ++bb) {
-                        const unsigned long long bal = __ballot((c >> bb) & 1);
-                        pre += __popcll(bal & lt) << bb;
-                        tot += __popcll(bal) << bb;
-                    }
-                    int pos = n1 + pre;
+                    int sc_ = c;
+                    sc_ += __builtin_amdgcn_update_dpp(0, c, 0x111, 0xf, 0xf, true);        // row_shr:1
+                    sc_ += __builtin_amdgcn_update_dpp(0, c, 0x112, 0xf, 0xf, true);        // row_shr:2
+                    sc_ += __builtin_amdgcn_update_dpp(0, c, 0x113, 0xf, 0xf, true);        // row_shr:3
+                    sc_ += __builtin_amdgcn_update_dpp(0, sc_, 0x114, 0xf, 0xe, true);      // row_shr:4
+                    sc_ += __builtin_amdgcn_update_dpp(0, sc_, 0x118, 0xf, 0xc, true);      // row_shr:8
+                    sc_ += __builtin_amdgcn_update_dpp(0, sc_, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1,3
+                    sc_ += __builtin_amdgcn_update_dpp(0, sc_, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2,3
+                    const int tot = __builtin_amdgcn_readlane(sc_, 63);
+                    int pos = n1 + sc_ - c;
                     u32 mm = m;
                     while (mm) {
-                        const int bpx = __builtin_ctz(mm);
-                        q[pos++] = (u16)((ty << 9) | (tx8 + bpx));
+                        const int bp = __builtin_ctz(mm);
+                        q[pos++] = (u16)((ty << 9) | (tx8 + (bp >> 2)));
                         mm &= mm - 1;
                     }
                     n1 += tot;
@@ -499,18 +512,18 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
                 if (n3 > 0) break;
             }
         }
-        // ---- row-major rank (queue keys ty<<9|tx are row-major) and packed store
+        // ---- packed store.  The queue is row-major by construction: the quick reject appends iteration by iteration
+        // (ascending rows), lanes in (row, column) order through the wave prefix, pixels of a lane in ascending x; the two
+        // in-place compactions are stable.  cv::FAST emits in the same order, so entry e is candidate e of the cell.
         u32* out = candEnt + (size_t)frame * g.totalSlots + cell.slot;
         for (int e0 = 0; e0 < n3; e0 += 64) {
             const int e = e0 + lane;
-            const int my = e < n3 ? q[e] : 0xFFFF;
-            int rank = 0;
-            for (int j = 0; j < n3; ++j) rank += q[j] < my;
             if (e < n3) {
+                const int my = q[e];
                 const int tx = my & 511, ty = my >> 9;
                 const int s = sc[ty * Pb + tx];
-                if (rank < L.slotCap)
-                    out[rank] = (u32)(st.xal + tx - 16) | ((u32)(st.y0 + ty - 16) << 12) | ((u32)s << 24);
+                if (e < L.slotCap)
+                    out[e] = (u32)(st.xal + tx - 16) | ((u32)(st.y0 + ty - 16) << 12) | ((u32)s << 24);
                 else atomicExch(err, 1);
             }
         }
