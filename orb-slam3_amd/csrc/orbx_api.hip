@@ -46,8 +46,11 @@ struct orbx {
     std::vector<StripInfo> strips;
     StripInfo* dStrips = nullptr; size_t capStrips = 0;
     bool fastV1 = false;
-    int f3Tile = 0, f3Qcap = 0;
-    size_t f3Lds = 0;
+    // k_fast3 launch groups: level 0 (needs no resize), the fine levels, the coarse levels.  Each group sizes its own LDS
+    // (tile of its tallest cell row + survivor queues), because occupancy -- 20 vs 28 waves per CU -- is worth ~15 %.
+    struct F3Group { int strip0 = 0, nstrips = 0, tile = 0, qcap = 0; size_t lds = 0; };
+    std::vector<F3Group> f3g;
+    std::vector<int> stripTile, stripQ;                       // per strip: tile bytes, worst-case queue entries
     std::vector<RzTab> xt, yt;
     std::vector<RzX4> x4;
     std::vector<RzTask> rzTasks[12];
@@ -65,7 +68,6 @@ struct orbx {
     hipEvent_t* ev = evr[0];
     hipEvent_t evDone = nullptr;
     long nEnq = 0;
-    int nStrips0 = 0;
     u8 *dPyr = nullptr, *dBlur = nullptr, *dL0 = nullptr;
     const u8** dL0Ptr = nullptr;
     CellInfo* dCells = nullptr; BlurTask* dTiles = nullptr; RzTab *dXt = nullptr, *dYt = nullptr;
@@ -75,6 +77,9 @@ struct orbx {
     int maxCells = 0;
     KpOut* dKps = nullptr; u8* dDesc = nullptr; KpWork* dWork = nullptr;
     int *dN = nullptr, *dMono = nullptr, *dLap = nullptr, *dErr = nullptr;
+    u32 *dOvf = nullptr, *dOvfList = nullptr;                  // k_fast3 queue overflow list -> k_fast_fix
+    size_t capOvfList = 0;
+    int f3QcapForce = 0;                                       // ORBX_FAST_QCAP: test knob, forces a small queue
     int8_t* dPattern = nullptr;
     size_t capL0 = 0, capPyr = 0, capCells = 0, capTiles = 0, capXt = 0, capYt = 0, capCandCnt = 0, capCandEnt = 0, capSel = 0;
     int lastBatch = 0;
@@ -101,7 +106,7 @@ static int build_geometry(orbx* o, int w, int h) {
     memset(&g, 0, sizeof g);
     const int L = o->nlevels;
     g.nlevels = L; g.w0 = w; g.h0 = h; g.iniTh = o->iniTh; g.minTh = o->minTh; g.lowTh = std::min(o->iniTh, o->minTh);
-    o->cells.clear(); o->tiles.clear(); o->strips.clear(); o->f3Tile = 0; o->f3Qcap = 0; o->xt.clear(); o->yt.clear(); o->x4.clear(); for (auto& v : o->rzTasks) v.clear();
+    o->cells.clear(); o->tiles.clear(); o->strips.clear(); o->f3g.clear(); o->stripTile.clear(); o->stripQ.clear(); o->xt.clear(); o->yt.clear(); o->x4.clear(); for (auto& v : o->rzTasks) v.clear();
     size_t off = 0;
     int totalSlots = 0, totalSel = 0, maxN = 0;
     int64_t sumAll = 0, sumSrc = 0, sumDst = 0;
@@ -172,11 +177,12 @@ static int build_geometry(orbx* o, int w, int h) {
             st.level = (short)l; st.ncell = (short)n; st.x0 = f.x0; st.y0 = f.y0;
             st.w = (short)(last.x0 + last.cw - f.x0); st.h = (short)Hs; st.xal = (short)xal;
             st.lp = (short)align_up(needed, 16); st.cell0 = ci;
-            o->f3Tile = std::max(o->f3Tile, (int)st.lp * Hs);
+            int qworst = 64;
             for (int k = 0; k < n; ++k) {
                 const CellInfo& c = o->cells[ci + k];
-                o->f3Qcap = std::max(o->f3Qcap, align_up(std::max(0, c.cw - 6) * std::max(0, c.ch - 6), 64));
+                qworst = std::max(qworst, align_up(std::max(0, c.cw - 6) * std::max(0, c.ch - 6), 64));
             }
+            o->stripTile.push_back((int)st.lp * Hs); o->stripQ.push_back(qworst);
             o->strips.push_back(st);
             ci += n;
         }
@@ -310,12 +316,40 @@ static int build_geometry(orbx* o, int w, int h) {
     HIPCHK(hipMemcpy(o->dStrips, o->strips.data(), o->strips.size() * sizeof(StripInfo), hipMemcpyHostToDevice));
     if (!o->xt.empty()) HIPCHK(hipMemcpy(o->dXt, o->xt.data(), o->xt.size() * sizeof(RzTab), hipMemcpyHostToDevice));
     if (!o->yt.empty()) HIPCHK(hipMemcpy(o->dYt, o->yt.data(), o->yt.size() * sizeof(RzTab), hipMemcpyHostToDevice));
-    o->nStrips0 = 0;
-    for (const StripInfo& stp : o->strips) if (stp.level == 0) ++o->nStrips0;
-    o->f3Tile = align_up(o->f3Tile, 16);
-    o->f3Lds = (size_t)2 * o->f3Tile + (size_t)(F3_NT / 64) * o->f3Qcap * 2;
-    if (o->f3Lds > 160 * 1024 - 256) { set_err("FAST strip needs %zu B of LDS", o->f3Lds); return ORBX_E_UNSUPPORTED; }
-    HIPCHK(hipFuncSetAttribute((const void*)k_fast3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->f3Lds));
+    {   // FAST launch groups.  Boundaries: [level 0] [levels 1..k] [levels k+1..], k = the smallest level after which at most
+        // 15 % of the cells remain: the coarse levels have few cells, but the tallest cell rows (an image 102 rows high is
+        // cut into 2 cell rows of 51) and the densest corners, so they keep the worst-case queue.  The other groups bound the
+        // queue so that 7 workgroups fit a CU; a cell that overflows it is redone by k_fast_fix.
+        const int nS = (int)o->strips.size();
+        std::vector<int> cellsAfter(g.nlevels + 1, 0);
+        for (int l = g.nlevels - 1; l >= 0; --l) cellsAfter[l] = cellsAfter[l + 1] + g.lv[l].nCells;
+        int k = g.nlevels - 1;
+        while (k > 0 && cellsAfter[k] * 100 <= 15 * g.totalCells) --k;      // levels > k hold <= 15 % of the cells
+        int b0 = 0, b1 = 0;
+        for (const StripInfo& stp : o->strips) { if (stp.level == 0) ++b0; if (stp.level <= k) ++b1; }
+        const int bounds[4] = {0, b0, std::max(b0, b1), nS};
+        size_t maxLds = 0;
+        for (int gi = 0; gi < 3; ++gi) {
+            orbx::F3Group G;
+            G.strip0 = bounds[gi]; G.nstrips = bounds[gi + 1] - bounds[gi];
+            if (G.nstrips <= 0) continue;
+            int qworst = 64;
+            for (int si = G.strip0; si < G.strip0 + G.nstrips; ++si) { G.tile = std::max(G.tile, o->stripTile[si]); qworst = std::max(qworst, o->stripQ[si]); }
+            G.tile = align_up(G.tile, 16);
+            G.qcap = qworst;
+            if (gi < 2) {
+                const int budget = (160 * 1024 / 7 - 2 * G.tile) / (2 * (F3_NT / 64));
+                G.qcap = std::min(qworst, std::max(512, budget / 64 * 64));
+            }
+            if (o->f3QcapForce > 0) G.qcap = std::min(G.qcap, align_up(o->f3QcapForce, 64));
+            G.lds = (size_t)2 * G.tile + (size_t)(F3_NT / 64) * G.qcap * 2;
+            if (G.lds > 160 * 1024 - 256) { set_err("FAST strip needs %zu B of LDS", G.lds); return ORBX_E_UNSUPPORTED; }
+            maxLds = std::max(maxLds, G.lds);
+            o->f3g.push_back(G);
+        }
+        HIPCHK(hipFuncSetAttribute((const void*)k_fast3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
+    }
+    if (ensure(&o->dOvfList, &o->capOvfList, (size_t)g.totalCells * B)) return ORBX_E_HIP;
     HIPCHK(hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->qtLds));
     HIPCHK(hipFuncSetAttribute((const void*)k_quadtree2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->qt2Lds));
     o->curW = w; o->curH = h;
@@ -350,6 +384,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     o->fastV1 = getenv("ORBX_FAST_V1") != nullptr;
     o->qtV1 = getenv("ORBX_QT_V1") != nullptr;
     o->odV1 = getenv("ORBX_OD_V1") != nullptr;
+    if (const char* e = getenv("ORBX_FAST_QCAP")) o->f3QcapForce = atoi(e);
     o->serial = getenv("ORBX_SERIAL") != nullptr;            // A/B switch: simple per-cell reference kernel
     o->scaleFactor = scale_factor;                              // double member initialised from float (ORBextractor.h:96)
     const int L = nlevels;
@@ -378,8 +413,8 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
         if (hipMalloc((void**)&o->dL0Ptr, sizeof(u8*) * B) != hipSuccess || hipMalloc((void**)&o->dSelCnt, sizeof(u32) * 12 * B) != hipSuccess ||
             hipMalloc((void**)&o->dN, sizeof(int) * B) != hipSuccess || hipMalloc((void**)&o->dMono, sizeof(int) * B) != hipSuccess ||
             hipMalloc((void**)&o->dLap, sizeof(int) * 2 * B) != hipSuccess || hipMalloc((void**)&o->dErr, sizeof(int)) != hipSuccess ||
-            hipMalloc((void**)&o->dPattern, 1024) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
-        if (hipMemcpy(o->dPattern, kPattern, 1024, hipMemcpyHostToDevice) != hipSuccess || hipMemset(o->dErr, 0, sizeof(int)) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMemcpy failed"); break; }
+            hipMalloc((void**)&o->dPattern, 1024) != hipSuccess || hipMalloc((void**)&o->dOvf, 2 * sizeof(u32)) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
+        if (hipMemcpy(o->dPattern, kPattern, 1024, hipMemcpyHostToDevice) != hipSuccess || hipMemset(o->dErr, 0, sizeof(int)) != hipSuccess || hipMemset(o->dOvf, 0, 2 * sizeof(u32)) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMemcpy failed"); break; }
         o->hL0Ptr.resize(B); o->hLap.resize(2 * B);
         rc = build_geometry(o, max_w, max_h);
     } while (0);
@@ -394,7 +429,7 @@ void orbx_destroy(orbx_t* o) {
     if (o->stream) (void)hipStreamSynchronize(o->stream);
     if (o->stream2) (void)hipStreamSynchronize(o->stream2);
     void* ptrs[] = {o->dPyr, o->dBlur, o->dL0, (void*)o->dL0Ptr, o->dCells, o->dTiles, o->dStrips, o->dX4, o->dRzTasks, o->dXt, o->dYt, o->dCandCnt, o->dCandEnt,
-                    o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->dKps, o->dDesc, o->dWork, o->dN, o->dMono, o->dLap, o->dErr, o->dPattern};
+                    o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->dKps, o->dDesc, o->dWork, o->dN, o->dMono, o->dLap, o->dErr, o->dPattern, o->dOvf, o->dOvfList};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& set : o->evr) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     if (o->evDone) (void)hipEventDestroy(o->evDone);
@@ -471,15 +506,25 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
                            o->dCandCnt, o->dCandEnt, o->dErr);
         HIPCHK(hipEventRecord(o->ev[10], st));
     } else {
-        const unsigned n0 = (unsigned)o->nStrips0, nAll = (unsigned)o->strips.size();
-        hipLaunchKernelGGL(k_fast3, dim3(n0, nimg), dim3(F3_NT), o->f3Lds, st, g, o->dL0Ptr, l0pitch, o->dPyr,
-                           o->dCells, o->dStrips, o->dCandCnt, o->dCandEnt, o->dErr, o->f3Tile, o->f3Qcap);
-        HIPCHK(hipEventRecord(o->ev[10], st));                   // level-0 FAST done
-        HIPCHK(hipStreamWaitEvent(st, o->ev[8], 0));
-        HIPCHK(hipEventRecord(o->ev[1], st));
-        if (nAll > n0)
-            hipLaunchKernelGGL(k_fast3, dim3(nAll - n0, nimg), dim3(F3_NT), o->f3Lds, st, g, o->dL0Ptr, l0pitch, o->dPyr,
-                               o->dCells, o->dStrips + n0, o->dCandCnt, o->dCandEnt, o->dErr, o->f3Tile, o->f3Qcap);
+        bool waited = false;
+        for (const orbx::F3Group& G : o->f3g) {
+            const bool lvl0 = o->strips[G.strip0].level == 0;
+            if (!lvl0 && !waited) {
+                HIPCHK(hipEventRecord(o->ev[10], st));           // level-0 FAST done
+                HIPCHK(hipStreamWaitEvent(st, o->ev[8], 0));
+                HIPCHK(hipEventRecord(o->ev[1], st));
+                waited = true;
+            }
+            hipLaunchKernelGGL(k_fast3, dim3((unsigned)G.nstrips, nimg), dim3(F3_NT), G.lds, st, g, o->dL0Ptr, l0pitch, o->dPyr,
+                               o->dCells, o->dStrips + G.strip0, o->dCandCnt, o->dCandEnt, o->dErr, G.tile, G.qcap, o->dOvf, o->dOvfList);
+        }
+        if (!waited) {                                           // single-level extractor
+            HIPCHK(hipEventRecord(o->ev[10], st));
+            HIPCHK(hipStreamWaitEvent(st, o->ev[8], 0));
+            HIPCHK(hipEventRecord(o->ev[1], st));
+        }
+        hipLaunchKernelGGL(k_fast_fix, dim3(512), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dCells, o->dCandCnt, o->dCandEnt,
+                           o->dErr, o->dOvf, o->dOvfList);
     }
     HIPCHK(hipEventRecord(o->ev[2], st));
     // blur (VALU + HBM) runs beside the quadtree (LDS-latency bound), not beside FAST (VALU bound)

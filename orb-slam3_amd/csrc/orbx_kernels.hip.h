@@ -247,15 +247,14 @@ __device__ __forceinline__ int fast_score16(const u8* t, int p) {
 // Output: packed (x | y<<12 | S<<24) in row-major order into the cell's slot array + its count.
 // ------------------------------------------------------------------------------------------------
 #define ORBX_FAST_TILE 6400
-__global__ __launch_bounds__(256) void k_fast(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
-                                              const CellInfo* __restrict__ cells, u32* candCnt, u32* candEnt,
-                                              int* err) {
+__device__ __forceinline__ void fast_cell_block(const Geom& g, const u8* const* l0, int l0pitch, const u8* pyr,
+                                                const CellInfo* __restrict__ cells, u32* candCnt, u32* candEnt,
+                                                int* err, int cellIdx, int frame) {
     __shared__ u8 tile[ORBX_FAST_TILE];
     __shared__ u8 sc[ORBX_FAST_TILE];
     __shared__ int s_cntIni;
     __shared__ int s_wave[4];
-    const CellInfo c = cells[blockIdx.x];
-    const int frame = blockIdx.y;
+    const CellInfo c = cells[cellIdx];
     const int tid = threadIdx.x;
     const int cw = c.cw, ch = c.ch;
     int sp;
@@ -318,6 +317,29 @@ __global__ __launch_bounds__(256) void k_fast(Geom g, const u8* const* l0, int l
     if (tid == 0) candCnt[(size_t)frame * g.totalCells + c.cnt] = (u32)base;
 }
 
+__global__ __launch_bounds__(256) void k_fast(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
+                                              const CellInfo* __restrict__ cells, u32* candCnt, u32* candEnt,
+                                              int* err) {
+    fast_cell_block(g, l0, l0pitch, pyr, cells, candCnt, candEnt, err, blockIdx.x, blockIdx.y);
+}
+
+// k_fast_fix: cells whose quick-reject survivors did not fit k_fast3's bounded LDS queue (rare: the queue holds 500+
+// of a cell's ~1400 pixels; a dense-corner texture is needed) are redone here by the per-cell kernel body, which has no
+// queue.  ovf[0] = number of entries, ovf[1] = workgroups finished (the last one re-arms both for the next batch).
+__global__ __launch_bounds__(256) void k_fast_fix(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
+                                                  const CellInfo* __restrict__ cells, u32* candCnt, u32* candEnt,
+                                                  int* err, u32* ovf, const u32* __restrict__ ovfList) {
+    const u32 n = __builtin_amdgcn_readfirstlane(ovf[0]);
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+        const u32 e = ovfList[i];
+        const int frame = (int)(e / (u32)g.totalCells);
+        fast_cell_block(g, l0, l0pitch, pyr, cells, candCnt, candEnt, err, (int)(e - (u32)frame * g.totalCells), frame);
+        __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&ovf[1], 1u) == gridDim.x - 1) { ovf[0] = 0; ovf[1] = 0; }
+}
+
 struct StripInfo { short level, ncell, x0, y0, w, h, xal, lp; int cell0; };   // lp = LDS tile pitch in bytes
 
 // ------------------------------------------------------------------------------------------------
@@ -325,15 +347,17 @@ struct StripInfo { short level, ncell, x0, y0, w, h, xal, lp; int cell0; };   //
 // workgroup barrier after the tile load (k_fast2 spent its time parked at 7 barriers with 2 WGs/CU).
 // Per cell the wave replays the reference literally: cv::FAST at iniTh, and only if that leaves the cell
 // empty AFTER non-max suppression, cv::FAST at minTh (ORBextractor.cc:1112-1125):
-//   quick reject (packed 16-bit, 4 px per lane) -> ballot compaction into the wave's LDS queue ->
-//   exact score on dense lanes, in-place compaction of pixels with S >= t -> strict 3x3 maxima inside the
-//   cell window, compacted again -> row-major rank by counting (queue keys are row-major) -> packed store.
-// No atomics, no bitmap: all counts live in wave-uniform registers.
+//   quick reject (packed 16-bit, 8 px per lane, sign bits gathered by v_perm) -> DPP prefix scan -> the wave's LDS queue
+//   -> exact score on dense lanes, in-place compaction of pixels with S >= t -> strict 3x3 maxima inside the cell
+//   window, compacted again -> packed store (the queue stays row-major throughout, which is cv::FAST's order).
+// No atomics, no bitmap: all counts live in wave-uniform registers.  The queue is bounded (occupancy); a cell whose
+// survivors do not fit is handed to k_fast_fix through a global list.
 // ------------------------------------------------------------------------------------------------
 #define F3_NT 256
 __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
                                                  const CellInfo* __restrict__ cells, const StripInfo* __restrict__ strips,
-                                                 u32* candCnt, u32* candEnt, int* err, int tileBytes, int qcap) {
+                                                 u32* candCnt, u32* candEnt, int* err, int tileBytes, int qcap,
+                                                 u32* ovf, u32* ovfList) {
     extern __shared__ __attribute__((aligned(16))) unsigned char f3smem[];
     u8* img = f3smem;
     u8* sc = f3smem + tileBytes;
@@ -388,6 +412,7 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
         const int cx0 = cell.x0 + 3 - st.xal, cx1 = cell.x0 + cell.cw - 3 - st.xal;   // valid columns (tile coords)
         const int vy0 = 3, vy1 = H - 3;
         int n3 = 0;
+        bool ovfl = false;                                                // survivors of the quick reject exceed the queue
         if (cx1 > cx0 && vy1 > vy0) {
             // lane -> (row offset lr, 8-px column lc): ncol columns cover [cx0, cx1), rpi rows per wave-iteration
             const int c80 = cx0 >> 3, ncol = ((cx1 + 7) >> 3) - c80, nrow = vy1 - vy0;
@@ -461,6 +486,7 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
                     sc_ += __builtin_amdgcn_update_dpp(0, sc_, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1,3
                     sc_ += __builtin_amdgcn_update_dpp(0, sc_, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2,3
                     const int tot = __builtin_amdgcn_readlane(sc_, 63);
+                    if (n1 + tot > qcap) { ovfl = true; break; }             // wave-uniform; the cell goes to k_fast_fix
                     int pos = n1 + sc_ - c;
                     u32 mm = m;
                     while (mm) {
@@ -470,6 +496,7 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
                     }
                     n1 += tot;
                 }
+                if (ovfl) break;
 #ifdef F3_ABL_NOSCORE
                 n1 = 0;
 #endif
@@ -511,6 +538,10 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
                 }
                 if (n3 > 0) break;
             }
+        }
+        if (ovfl) {
+            if (lane == 0) ovfList[atomicAdd(&ovf[0], 1u)] = (u32)frame * (u32)g.totalCells + (u32)(st.cell0 + c);
+            continue;
         }
         // ---- packed store.  The queue is row-major by construction: the quick reject appends iteration by iteration
         // (ascending rows), lanes in (row, column) order through the wave prefix, pixels of a lane in ascending x; the two

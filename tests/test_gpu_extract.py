@@ -146,3 +146,23 @@ def test_ab_reference_kernels_stay_bit_exact(pkg, oracle, synth, monkeypatch):
         for e in env:
             monkeypatch.delenv(e)
         assert mono == mono_ref and kps.tobytes() == kps_ref.tobytes() and np.array_equal(desc, desc_ref), env
+
+
+@pytest.mark.parametrize("qcap", [64, 128, 256])
+def test_fast_queue_overflow_cells_are_redone(pkg, oracle, synth, monkeypatch, qcap):
+    """k_fast3 keeps a bounded LDS queue per cell; cells whose quick-reject survivors exceed it are redone by k_fast_fix.
+    ORBX_FAST_QCAP forces a tiny queue so that many (64) or a few (256) cells take that route; two batches in a row also
+    check that the overflow list is re-armed."""
+    imgs = [synth.gen_image(752, 480, 31 + i) for i in range(3)]
+    ref = oracle.Extractor(1000)
+    monkeypatch.setenv("ORBX_FAST_QCAP", str(qcap))
+    ex = pkg.ORBextractor(1000, max_size=(752, 480), max_batch=3)
+    monkeypatch.delenv("ORBX_FAST_QCAP")
+    try:
+        for rep in range(2):
+            out = ex.extract_batch(imgs, [(0, 1000)] * 3)
+            for img, (mono, kps, desc) in zip(imgs, out):
+                n_ref, kps_ref, desc_ref, mono_ref = ref(img, (0, 1000))
+                assert mono == mono_ref and kps.tobytes() == kps_ref.tobytes() and np.array_equal(desc, desc_ref)
+    finally:
+        ex.close()
