@@ -48,7 +48,8 @@ struct orbx {
     bool fastV1 = false;
     // k_fast3 launch groups: level 0 (needs no resize), the fine levels, the coarse levels.  Each group sizes its own LDS
     // (tile of its tallest cell row + survivor queues), because occupancy -- 20 vs 28 waves per CU -- is worth ~15 %.
-    struct F3Group { int strip0 = 0, nstrips = 0, tile = 0, qcap = 0; size_t lds = 0; };
+    struct F3Group { int strip0 = 0, nstrips = 0, tile = 0, qcap = 0, lastLevel = 0; size_t lds = 0; };
+    hipEvent_t evLvl[12] = {};                                // "pyramid level l is resized" for the levels that end a FAST group
     std::vector<F3Group> f3g;
     std::vector<int> stripTile, stripQ;                       // per strip: tile bytes, worst-case queue entries
     std::vector<RzTab> xt, yt;
@@ -337,6 +338,7 @@ static int build_geometry(orbx* o, int w, int h) {
             int qworst = 64;
             for (int si = G.strip0; si < G.strip0 + G.nstrips; ++si) { G.tile = std::max(G.tile, o->stripTile[si]); qworst = std::max(qworst, o->stripQ[si]); }
             G.tile = align_up(G.tile, 16);
+            G.lastLevel = o->strips[G.strip0 + G.nstrips - 1].level;
             G.qcap = qworst;
             if (gi < 2) {
                 const int budget = (160 * 1024 / 7 - 2 * G.tile) / (2 * (F3_NT / 64));
@@ -408,6 +410,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     do {
         if (hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&o->stream2, hipStreamNonBlocking) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipStreamCreate failed"); break; }
         for (auto& set : o->evr) for (auto& e : set) if (rc == ORBX_OK && hipEventCreate(&e) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
+        for (auto& e : o->evLvl) if (rc == ORBX_OK && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
         if (rc == ORBX_OK && hipEventCreateWithFlags(&o->evDone, hipEventDisableTiming) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
         if (rc) break;
         const size_t B = max_batch;
@@ -434,6 +437,7 @@ void orbx_destroy(orbx_t* o) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& set : o->evr) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     if (o->evDone) (void)hipEventDestroy(o->evDone);
+    for (auto& e : o->evLvl) if (e) (void)hipEventDestroy(e);
     if (o->stream) (void)hipStreamDestroy(o->stream);
     if (o->stream2) (void)hipStreamDestroy(o->stream2);
     delete o;
@@ -506,6 +510,8 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
             dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, nimg), block(64, 4);
             hipLaunchKernelGGL(k_resize, grid, block, 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, l, o->dXt, o->dYt);
         }
+        if (!o->fastV1 && l < g.nlevels - 1)
+            for (const orbx::F3Group& G : o->f3g) if (G.lastLevel == l) HIPCHK(hipEventRecord(o->evLvl[l], s1));
     }
     HIPCHK(hipEventRecord(o->ev[8], s1));                        // pyramid ready
     if (o->fastV1) {
@@ -515,23 +521,25 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
                            o->dCandCnt, o->dCandEnt, o->dErr);
         HIPCHK(hipEventRecord(o->ev[10], st));
     } else {
-        bool waited = false;
+        // every group waits only for the pyramid levels it reads: the fine levels start while the coarse ones are still
+        // being resized (the 7 resizes are a dependent chain of small kernels, ~160 us)
+        bool first = true;
         for (const orbx::F3Group& G : o->f3g) {
-            const bool lvl0 = o->strips[G.strip0].level == 0;
-            if (!lvl0 && !waited) {
-                HIPCHK(hipEventRecord(o->ev[10], st));           // level-0 FAST done
-                HIPCHK(hipStreamWaitEvent(st, o->ev[8], 0));
-                HIPCHK(hipEventRecord(o->ev[1], st));
-                waited = true;
+            const bool lvl0 = G.lastLevel == 0;
+            if (!lvl0) {
+                if (first) HIPCHK(hipEventRecord(o->ev[10], st));   // level-0 FAST done
+                HIPCHK(hipStreamWaitEvent(st, G.lastLevel < g.nlevels - 1 ? o->evLvl[G.lastLevel] : o->ev[8], 0));
+                if (first) HIPCHK(hipEventRecord(o->ev[1], st));
+                first = false;
             }
             hipLaunchKernelGGL(k_fast3, dim3((unsigned)G.nstrips, nimg), dim3(F3_NT), G.lds, st, g, o->dL0Ptr, l0pitch, o->dPyr,
                                o->dCells, o->dStrips + G.strip0, o->dCandCnt, o->dCandEnt, o->dErr, G.tile, G.qcap, o->dOvf, o->dOvfList);
         }
-        if (!waited) {                                           // single-level extractor
+        if (first) {                                             // single-level extractor
             HIPCHK(hipEventRecord(o->ev[10], st));
-            HIPCHK(hipStreamWaitEvent(st, o->ev[8], 0));
             HIPCHK(hipEventRecord(o->ev[1], st));
         }
+        HIPCHK(hipStreamWaitEvent(st, o->ev[8], 0));             // later stages read every level
         hipLaunchKernelGGL(k_fast_fix, dim3(512), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dCells, o->dCandCnt, o->dCandEnt,
                            o->dErr, o->dOvf, o->dOvfList);
     }
