@@ -551,11 +551,11 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
                        o->dTiles, (int)o->tiles.size(), o->blurSel);
     HIPCHK(hipEventRecord(o->ev[9], s1));                        // blur ready
     if (o->qtV1)
-        hipLaunchKernelGGL(k_quadtree, dim3(g.nlevels, nimg), dim3(256), o->qtLds, st, g, o->dCells, o->dCandCnt, o->dCandEnt,
+        hipLaunchKernelGGL(k_quadtree, dim3(nimg, g.nlevels), dim3(256), o->qtLds, st, g, o->dCells, o->dCandCnt, o->dCandEnt,
                            o->dKpNode, o->dSel, o->dSelCnt, o->dErr);
     else {
         Geom g2 = g; g2.nodeCap = o->qt2Cap; g2.sortCap = o->qt2Sort;
-        hipLaunchKernelGGL(k_quadtree2, dim3(g.nlevels, nimg), dim3(256), o->qt2Lds, st, g2, o->dCandCnt, o->dCandEnt,
+        hipLaunchKernelGGL(k_quadtree2, dim3(nimg, g.nlevels), dim3(256), o->qt2Lds, st, g2, o->dCandCnt, o->dCandEnt,
                            o->dDense, o->dKpNode, o->dSel, o->dSelCnt, o->dErr, o->maxCells);
     }
     HIPCHK(hipEventRecord(o->ev[3], st));

@@ -586,7 +586,9 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const CellInfo* __rest
                                                   const u32* __restrict__ candCnt, const u32* __restrict__ candEnt,
                                                   u16* kpNode, u32* selOut, u32* selCnt, int* err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int level = blockIdx.x, frame = blockIdx.y;
+    // grid = (frames, levels): consecutive workgroup ids go round-robin over the 8 XCDs, so the fastest-varying index must
+    // be the frame -- with the level there and 8 levels, every level-0 (heaviest) workgroup would land on the same XCD
+    const int level = blockIdx.y, frame = blockIdx.x;
     const LevelDesc& L = g.lv[level];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int cap = g.nodeCap;
@@ -851,7 +853,9 @@ __device__ __forceinline__ short4 qt_child_rect(short4 r, int q) {
 __global__ __launch_bounds__(256) void k_quadtree2(Geom g, const u32* __restrict__ candCnt, const u32* __restrict__ candEnt,
                                                    u32* dense, u16* kpNode, u32* selOut, u32* selCnt, int* err, int maxCells) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int level = blockIdx.x, frame = blockIdx.y;
+    // grid = (frames, levels): consecutive workgroup ids go round-robin over the 8 XCDs, so the fastest-varying index must
+    // be the frame -- with the level there and 8 levels, every level-0 (heaviest) workgroup would land on the same XCD
+    const int level = blockIdx.y, frame = blockIdx.x;
     const LevelDesc& L = g.lv[level];
     const int tid = threadIdx.x;
     const int cap = g.nodeCap, n2cap = g.sortCap;
