@@ -1166,9 +1166,12 @@ __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int 
     const u32 selB = bs.selB[t.level], selC = bs.selC[t.level];
     const u32 K1 = 18u | (34u << 8) | (48u << 16) | (56u << 24), K2 = 48u | (34u << 8) | (18u << 16);
     const int nrows = min(BL_R, h - t.y0) + 6;
-    int hw[7][4];
+    // vertical window: Q[k][i] = (row sum of the previous source row, row sum of the row in slot k) as a u16 pair
+    // (row sums <= 256*255), so that the vertical 7-tap is four v_dot2_u32_u16 per pixel
+    u32 Q[7][4], hprev[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 7; ++k) { hw[k][0] = hw[k][1] = hw[k][2] = hw[k][3] = 0; }
+    for (int k = 0; k < 7; ++k) { Q[k][0] = Q[k][1] = Q[k][2] = Q[k][3] = 0; }
+    const us2 KA = as_us2(18u | (34u << 16)), KB = as_us2(48u | (56u << 16)), KC = as_us2(48u | (34u << 16)), KD = as_us2(18u << 16);
     // software pipeline: the loads of row group n+1 are issued BEFORE the arithmetic and stores of group n, so
     // waiting for them never waits for younger stores (vmcnt retires in issue order on gfx9)
     u32 Bn[7], Xn[7];
@@ -1209,19 +1212,23 @@ __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int 
                 const u32 w2[4] = {__builtin_amdgcn_alignbyte(C, Bf, 1), __builtin_amdgcn_alignbyte(C, Bf, 2),
                                    __builtin_amdgcn_alignbyte(C, Bf, 3), C};
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    hw[k][i] = (int)__builtin_amdgcn_udot4(w2[i], K2, __builtin_amdgcn_udot4(w1[i], K1, 0u, false), false);
+                for (int i = 0; i < 4; ++i) {
+                    const u32 hs = __builtin_amdgcn_udot4(w2[i], K2, __builtin_amdgcn_udot4(w1[i], K1, 0u, false), false);
+                    Q[k][i] = hprev[i] | (hs << 16);
+                    hprev[i] = hs;
+                }
                 if (r >= 6) {
-                    u32 packed = 0;
+                    // rows r-6..r: (r-6,r-5).(18,34) + (r-4,r-3).(48,56) + (r-2,r-1).(48,34) + (r-1,r).(0,18), + 0.5 ulp; the sum is
+                    // < 2^24, so the rounded result is byte 2 of the accumulator
+                    u32 acc[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        // operands fit 24 bits (row sums <= 2*65280): one v_mad_u32_u24 per tap pair
-                        u32 acc = mad24(56u, (u32)hw[(k + 4) % 7][i], 32768u);
-                        acc = mad24(48u, (u32)(hw[(k + 3) % 7][i] + hw[(k + 5) % 7][i]), acc);
-                        acc = mad24(34u, (u32)(hw[(k + 2) % 7][i] + hw[(k + 6) % 7][i]), acc);
-                        acc = mad24(18u, (u32)(hw[(k + 1) % 7][i] + hw[k][i]), acc);
-                        packed |= (acc >> 16) << (8 * i);
+                        u32 a = __builtin_amdgcn_udot2(as_us2(Q[(k + 2) % 7][i]), KA, 32768u, false);
+                        a = __builtin_amdgcn_udot2(as_us2(Q[(k + 4) % 7][i]), KB, a, false);
+                        a = __builtin_amdgcn_udot2(as_us2(Q[(k + 6) % 7][i]), KC, a, false);
+                        acc[i] = __builtin_amdgcn_udot2(as_us2(Q[k][i]), KD, a, false);
                     }
+                    const u32 packed = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u) | __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
                     if (gc <= gl) *(u32*)(dst + (size_t)(t.y0 + r - 6) * L.pitch + gc * 4) = packed;
                 }
             }
