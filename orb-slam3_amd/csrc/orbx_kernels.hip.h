@@ -212,28 +212,33 @@ __global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, in
 // ------------------------------------------------------------------------------------------------
 // FAST-9/16 score  S = max(A,B) - 1  (cv::cornerScore<16>), branch-free:
 //   B' = max_k min(ring[k..k+8]) ,  A' = min_k max(ring[k..k+8]) ;  A = v - A' , B = B' - v
-// 9-windows are built from 3-windows (min3/max3 map to v_min3/v_max3).
+// The 16 nine-windows are taken in pairs that share eight pixels W_j = ring[2j..2j+7]:
+//   max(min(W_j, r[2j+8]), min(r[2j-1], W_j)) = min(W_j, max(r[2j+8], r[2j-1]))
+// so B' = max_j min3(m4[j], m4[j+2], max(r[2j-1], r[2j+8])) with m4[j] = min(ring[2j..2j+3]) -- 36 min/max per side.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int fast_score16(const u8* t, int p) {
-    const int v = t[0];
+    // row bases at column -3 so that every LDS offset is a non-negative immediate
+    const u8* b0 = t - 3 * p - 3;
+    const u8 *b1 = b0 + p, *b2 = b1 + p, *b3 = b2 + p, *b4 = b3 + p, *b5 = b4 + p, *b6 = b5 + p;
     int r[16];
-    r[0] = t[3 * p];      r[1] = t[3 * p + 1];   r[2] = t[2 * p + 2];   r[3] = t[p + 3];
-    r[4] = t[3];          r[5] = t[-p + 3];      r[6] = t[-2 * p + 2];  r[7] = t[-3 * p + 1];
-    r[8] = t[-3 * p];     r[9] = t[-3 * p - 1];  r[10] = t[-2 * p - 2]; r[11] = t[-p - 3];
-    r[12] = t[-3];        r[13] = t[p - 3];      r[14] = t[2 * p - 2];  r[15] = t[3 * p - 1];
-    int lo3[16], hi3[16];
+    r[0] = b6[3];   r[1] = b6[4];   r[2] = b5[5];   r[3] = b4[6];
+    r[4] = b3[6];   r[5] = b2[6];   r[6] = b1[5];   r[7] = b0[4];
+    r[8] = b0[3];   r[9] = b0[2];   r[10] = b1[1];  r[11] = b2[0];
+    r[12] = b3[0];  r[13] = b4[0];  r[14] = b5[1];  r[15] = b6[2];
+    const int v = b3[3];
+    int m2[8], M2[8], m4[8], M4[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        lo3[k] = min(r[k], min(r[(k + 1) & 15], r[(k + 2) & 15]));
-        hi3[k] = max(r[k], max(r[(k + 1) & 15], r[(k + 2) & 15]));
-    }
+    for (int j = 0; j < 8; ++j) { m2[j] = min(r[2 * j], r[2 * j + 1]); M2[j] = max(r[2 * j], r[2 * j + 1]); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { m4[j] = min(m2[j], m2[(j + 1) & 7]); M4[j] = max(M2[j], M2[(j + 1) & 7]); }
     int bmax = 0, amin = 255;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int lo9 = min(lo3[k], min(lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
-        const int hi9 = max(hi3[k], max(hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
-        bmax = max(bmax, lo9);
-        amin = min(amin, hi9);
+    for (int j = 0; j < 8; ++j) {
+        const int a = r[(2 * j + 15) & 15], c = r[(2 * j + 8) & 15];
+        const int u = min(min(m4[j], m4[(j + 2) & 7]), max(a, c));
+        const int U = max(max(M4[j], M4[(j + 2) & 7]), min(a, c));
+        bmax = max(bmax, u);
+        amin = min(amin, U);
     }
     return max(v - amin, bmax - v) - 1;
 }
