@@ -92,6 +92,7 @@ int orbm_knn2_batch_async(orbm_t* m, const uint8_t* q, int q_stride, const int32
                           const int32_t* nt, int npairs, int max_nt, int32_t* idx2, int32_t* dist2) {
     (void)max_nt;
     if (!m || !q || !t || !nq || !nt || !idx2 || !dist2 || npairs < 1 || q_stride < 1 || t_stride < 1) return ORBM_E_INVALID;
+    if (t_stride >= (1 << 22)) { set_merr("knn2: more than 2^22 train descriptors per pair"); return ORBM_E_INVALID; }
     MHIPCHK(hipSetDevice(m->device));
     m->gridFirst = false;
     MHIPCHK(hipEventRecord(m->e0, m->stream));

@@ -12,6 +12,26 @@ __device__ __forceinline__ int ham256(const u64 a[4], u64 b0, u64 b1, u64 b2, u6
     return __popcll(a[0] ^ b0) + __popcll(a[1] ^ b1) + __popcll(a[2] ^ b2) + __popcll(a[3] ^ b3);
 }
 
+__device__ __forceinline__ unsigned bcnt_acc(unsigned x, unsigned acc) {   // popcount(x) + acc in one instruction
+#if __HIP_DEVICE_COMPILE__
+    unsigned r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+#else
+    return (unsigned)__builtin_popcount(x) + acc;
+#endif
+}
+
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
+#if __HIP_DEVICE_COMPILE__
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return max(min(a, b), min(max(a, b), c));
+#endif
+}
+
 // (dist, idx) lexicographic insert into a sorted top-2
 __device__ __forceinline__ void top2_insert(int d, int j, int& d0, int& j0, int& d1, int& j1) {
     if (d < d0 || (d == d0 && j < j0)) { d1 = d0; j1 = j0; d0 = d; j0 = j; }
@@ -31,7 +51,7 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int
     __shared__ __attribute__((aligned(16))) u64 tr[KNN_CHUNK * 4];
     __shared__ int mrg[4][64][4];
     const int pair = blockIdx.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nQ = nq[pair], nT = nt[pair];
     const int qi = blockIdx.x * 64 + lane;
     if (blockIdx.x * 64 >= nQ) return;                      // whole block idle (uniform)
@@ -42,7 +62,10 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int
         a[0] = (u64)lo.x | ((u64)lo.y << 32); a[1] = (u64)lo.z | ((u64)lo.w << 32);
         a[2] = (u64)hi.x | ((u64)hi.y << 32); a[3] = (u64)hi.z | ((u64)hi.w << 32);
     }
-    int d0 = 1 << 20, d1 = 1 << 20, j0 = -1, j1 = -1;
+    // top-2 as packed keys (distance << 22 | train index): unsigned order == (distance, index) lexicographic, which is the
+    // tie rule (lower train index first); one v_min + one v_med3 per candidate.  t_stride < 2^22 is checked by the host.
+    unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+    const unsigned* a32 = (const unsigned*)a;
     const uint8_t* tb = t + (size_t)pair * t_stride * 32;
     for (int c0 = 0; c0 < nT; c0 += KNN_CHUNK) {
         const int cn = min(KNN_CHUNK, nT - c0);
@@ -50,23 +73,36 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int
         for (int i = threadIdx.x; i < cn * 2; i += 256)       // 16 B per thread per step, coalesced
             ((uint4*)tr)[i] = ((const uint4*)(tb + (size_t)c0 * 32))[i];
         __syncthreads();
-        for (int j = wv; j < cn; j += 4) {
-            const int d = ham256(a, tr[4 * j], tr[4 * j + 1], tr[4 * j + 2], tr[4 * j + 3]);
-            const int jj = c0 + j;
-            if (d < d0) { d1 = d0; j1 = j0; d0 = d; j0 = jj; }    // per wave jj ascends: strict < keeps the lower index
-            else if (d < d1) { d1 = d; j1 = jj; }
-        }
+        const uint4* tv = (const uint4*)tr;
+        auto one = [&](int j) {
+            const uint4 lo = tv[2 * j], hi = tv[2 * j + 1];     // same address in every lane: LDS broadcast
+            unsigned d = bcnt_acc(a32[0] ^ lo.x, 0u);
+            d = bcnt_acc(a32[1] ^ lo.y, d); d = bcnt_acc(a32[2] ^ lo.z, d); d = bcnt_acc(a32[3] ^ lo.w, d);
+            d = bcnt_acc(a32[4] ^ hi.x, d); d = bcnt_acc(a32[5] ^ hi.y, d); d = bcnt_acc(a32[6] ^ hi.z, d);
+            d = bcnt_acc(a32[7] ^ hi.w, d);                                           // 8 xor + 8 accumulating v_bcnt
+            const unsigned key = (d << 22) | (unsigned)(c0 + j);
+            k1 = umed3(k0, k1, key);           // second smallest of {k0 <= k1, key}
+            k0 = min(k0, key);
+        };
+        int j = wv;
+        for (; j + 12 < cn; j += 16) { one(j); one(j + 4); one(j + 8); one(j + 12); }
+        for (; j < cn; j += 4) one(j);
     }
-    mrg[wv][lane][0] = d0; mrg[wv][lane][1] = j0; mrg[wv][lane][2] = d1; mrg[wv][lane][3] = j1;
+    __syncthreads();
+    unsigned* mk = (unsigned*)mrg;                            // [4][64][2] keys
+    mk[(wv * 64 + lane) * 2] = k0; mk[(wv * 64 + lane) * 2 + 1] = k1;
     __syncthreads();
     if (wv == 0 && qi < nQ) {
-        for (int w = 1; w < 4; ++w) {
-            if (mrg[w][lane][1] >= 0) top2_insert(mrg[w][lane][0], mrg[w][lane][1], d0, j0, d1, j1);
-            if (mrg[w][lane][3] >= 0) top2_insert(mrg[w][lane][2], mrg[w][lane][3], d0, j0, d1, j1);
-        }
+        for (int w = 1; w < 4; ++w)
+            for (int e = 0; e < 2; ++e) {
+                const unsigned key = mk[(w * 64 + lane) * 2 + e];
+                k1 = umed3(k0, k1, key);
+                k0 = min(k0, key);
+            }
         const size_t o = ((size_t)pair * q_stride + qi) * 2;
-        idx2[o] = j0; idx2[o + 1] = j1;
-        dist2[o] = j0 < 0 ? -1 : d0; dist2[o + 1] = j1 < 0 ? -1 : d1;
+        const bool h0 = k0 != 0xFFFFFFFFu, h1 = k1 != 0xFFFFFFFFu;
+        idx2[o] = h0 ? (int)(k0 & 0x3FFFFFu) : -1; idx2[o + 1] = h1 ? (int)(k1 & 0x3FFFFFu) : -1;
+        dist2[o] = h0 ? (int)(k0 >> 22) : -1; dist2[o + 1] = h1 ? (int)(k1 >> 22) : -1;
     }
 }
 
