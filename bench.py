@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step (a larger batch amortises the dependent resize chain and the latency-bound quadtree)")
     ap.add_argument("--width", type=int, default=752)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
