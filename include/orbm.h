@@ -230,6 +230,26 @@ int orbm_stereo_matches(orbm_t*, void* left_extractor, int frame_l, void* right_
                         int nl, const orbm_kp_t* kl, const uint8_t* dl, int nr, const orbm_kp_t* kr, const uint8_t* dr,
                         float mb, float mbf, float* uright, float* depth);
 
+/* SURVEY 8(f).2  Frame::UndistortKeyPoints (Frame.cc:924-970): cv::undistortPoints(points, K, D, R = I, P = newK) on the
+ * coordinates of n keypoints (other fields copied).  k / newk = (fx, fy, cx, cy); dist = (k1, k2, p1, p2[, k3 ...]),
+ * ndist <= 14.  dist[0] == 0 copies the input (Frame.cc:928-932).  space = ORBM_HOST | ORBM_DEVICE for kps and out. */
+int orbm_undistort_keypoints(orbm_t*, int space, const orbm_kp_t* kps, int n, const float* k, const float* dist, int ndist,
+                             const float* newk, orbm_kp_t* out);
+/* Frame::ComputeImageBounds (Frame.cc:977-1021): bounds[4] = (mnMinX, mnMaxX, mnMinY, mnMaxY) (host output). */
+int orbm_image_bounds(orbm_t*, int cols, int rows, const float* k, const float* dist, int ndist, const float* newk, float* bounds);
+
+/* SURVEY 8(f).3  Frame::isInFrustum (Nleft == -1; Frame.cc:603-671) + MapPoint::PredictScale (MapPoint.cc:725-740) +
+ * Pinhole::project for n map points: the producer of the arrays orbm_search_by_projection_points consumes.
+ * pw / normal: [n][3] world position and mean viewing direction; min_dist / max_dist: mfMinDistance / mfMaxDistance;
+ * rcw[9] row-major, tcw[3], ow[3]; k = (fx, fy, cx, cy); bounds = (minX, maxX, minY, maxY); bf = mbf.
+ * Outputs mirror the MapPoint members: in_view (mbTrackInView), proj_x / proj_y (mTrackProjX/Y, -1 unless the point
+ * passed the image-bounds test), proj_xr, depth (mTrackDepth), level (mnTrackScaleLevel), view_cos -- the last four are
+ * written only where in_view.  All arrays in `space`.  Returns the number of points in view (host space) or 0. */
+int orbm_is_in_frustum(orbm_t*, int space, int n, const float* pw, const float* normal, const float* min_dist, const float* max_dist,
+                       const float* rcw, const float* tcw, const float* ow, const float* k, const float* bounds,
+                       float bf, float viewing_cos_limit, float log_scale_factor, int n_scale_levels,
+                       uint8_t* in_view, float* proj_x, float* proj_y, float* proj_xr, float* depth, int32_t* level, float* view_cos);
+
 #ifdef __cplusplus
 }
 #endif

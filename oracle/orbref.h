@@ -199,6 +199,27 @@ int orbref_stereo_matches(const orbref_t* left, const orbref_t* right,
                           int nl, const orbref_kp_t* kl, const uint8_t* dl, int nr, const orbref_kp_t* kr, const uint8_t* dr,
                           float mb, float mbf, float* uright, float* depth);
 
+/* Frame::UndistortKeyPoints (Frame.cc:924-970): cv::undistortPoints(pts, K, D, R = I, P = newK) on keypoint
+ * coordinates.  OpenCV's routine is restated (cvUndistortPointsInternal: double arithmetic, exactly 5 fixed-point
+ * iterations -- TermCriteria(MAX_ITER, 5, 0.01) -- with the `icdist < 0` bail-out; rational/thin-prism terms are zero for
+ * the 4/5-coefficient models ORB-SLAM3 configures).  k = (fx, fy, cx, cy); dist = (k1, k2, p1, p2[, k3]).  dist[0] == 0
+ * copies the input (Frame.cc:928-932).  Other keypoint fields are copied.  OpenCV version unpinned -> parity unpinned. */
+int orbref_undistort_keypoints(const orbref_kp_t* kps, int n, const float* k, const float* dist, int ndist, const float* newk,
+                               orbref_kp_t* out);
+/* Frame::ComputeImageBounds (Frame.cc:977-1021): bounds = (minX, maxX, minY, maxY) from the four undistorted corners. */
+int orbref_image_bounds(int cols, int rows, const float* k, const float* dist, int ndist, const float* newk, float* bounds);
+/* Frame::isInFrustum, Nleft == -1 branch (Frame.cc:603-671) + MapPoint::PredictScale (MapPoint.cc:725-740) +
+ * Pinhole::project (Pinhole.cpp:44-62) for n map points.  rcw[9] row-major, tcw[3], ow[3] = camera centre,
+ * k = (fx, fy, cx, cy), bounds = (minX, maxX, minY, maxY); min_dist / max_dist are mfMinDistance / mfMaxDistance (the
+ * 0.8 / 1.2 invariance factors are applied here, MapPoint.cc:668-681).  Outputs as the MapPoint members:
+ * in_view (mbTrackInView), proj_x/proj_y (-1 unless the point passed the image-bounds test, Frame.cc:607-608,637-638),
+ * proj_xr, depth (mTrackDepth = |Pc|), level (mnTrackScaleLevel), view_cos; the last four only where in_view. Returns
+ * the number of points in view. */
+int orbref_is_in_frustum(int n, const float* pw, const float* normal, const float* min_dist, const float* max_dist,
+                         const float* rcw, const float* tcw, const float* ow, const float* k, const float* bounds,
+                         float bf, float viewing_cos_limit, float log_scale_factor, int n_scale_levels,
+                         uint8_t* in_view, float* proj_x, float* proj_y, float* proj_xr, float* depth, int32_t* level, float* view_cos);
+
 #ifdef __cplusplus
 }
 #endif

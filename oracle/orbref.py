@@ -195,6 +195,8 @@ def _oracle_matcher_class():
     L.orbref_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_float, C.c_float, C.c_void_p, C.c_void_p]
 
+    pkg._bind_frame_geometry(L, "orbref_")
+
     class OracleMatcher(pkg._SearchMixin):
         _prefix = "orbref_"
 
@@ -216,6 +218,8 @@ def _oracle_matcher_class():
                                         float(mb), float(mbf), _p(ur), _p(dp))
             return n, ur[:len(kl)], dp[:len(kl)]
 
+    for name, fn in pkg._frame_geometry_methods("orbref_").items():
+        setattr(OracleMatcher, name, fn)
     return OracleMatcher
 
 

@@ -873,4 +873,101 @@ int orbref_stereo_matches(const orbref_t* left, const orbref_t* right,
     return kept;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// cv::undistortPoints restated (OpenCV imgproc undistort.dispatch.cpp, cvUndistortPointsInternal): double arithmetic,
+// 5 iterations, R = I so the final rotation/projection is  x' = P00*x + P01*y + P02  with P01 = 0, w = 1/(0*x + 0*y + 1).
+// ---------------------------------------------------------------------------------------------------------
+static void undistort_point(double u, double v, const double k[14], double fx, double fy, double cx, double cy,
+                            double nfx, double nfy, double ncx, double ncy, float* ox, float* oy) {
+    const double ifx = 1.0 / fx, ify = 1.0 / fy;
+    double x = (u - cx) * ifx, y = (v - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; ++j) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+        const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+        const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = nfx * x + 0.0 * y + ncx, yy = 0.0 * x + nfy * y + ncy, ww = 1.0 / (0.0 * x + 0.0 * y + 1.0);
+    *ox = (float)(xx * ww); *oy = (float)(yy * ww);
+}
+
+static void load_dist(const float* dist, int ndist, double k[14]) {
+    for (int i = 0; i < 14; ++i) k[i] = 0.0;
+    for (int i = 0; i < ndist && i < 14; ++i) k[i] = (double)dist[i];
+}
+
+int orbref_undistort_keypoints(const orbref_kp_t* kps, int n, const float* kk, const float* dist, int ndist, const float* newk,
+                               orbref_kp_t* out) {
+    if (n < 0 || !kk || !newk || (ndist > 0 && !dist)) return -2;
+    for (int i = 0; i < n; ++i) out[i] = kps[i];
+    if (ndist < 1 || dist[0] == 0.0f) return n;                      // Frame.cc:928-932
+    double k[14]; load_dist(dist, ndist, k);
+    for (int i = 0; i < n; ++i)
+        undistort_point((double)kps[i].x, (double)kps[i].y, k, kk[0], kk[1], kk[2], kk[3], newk[0], newk[1], newk[2], newk[3],
+                        &out[i].x, &out[i].y);
+    return n;
+}
+
+int orbref_image_bounds(int cols, int rows, const float* kk, const float* dist, int ndist, const float* newk, float* bounds) {
+    if (!kk || !newk || !bounds) return -2;
+    if (ndist < 1 || dist[0] == 0.0f) { bounds[0] = 0.f; bounds[1] = (float)cols; bounds[2] = 0.f; bounds[3] = (float)rows; return 0; }
+    double k[14]; load_dist(dist, ndist, k);
+    const float cxs[4] = {0.f, (float)cols, 0.f, (float)cols}, cys[4] = {0.f, 0.f, (float)rows, (float)rows};
+    float ux[4], uy[4];
+    for (int i = 0; i < 4; ++i)
+        undistort_point((double)cxs[i], (double)cys[i], k, kk[0], kk[1], kk[2], kk[3], newk[0], newk[1], newk[2], newk[3], &ux[i], &uy[i]);
+    bounds[0] = std::min(ux[0], ux[2]); bounds[1] = std::max(ux[1], ux[3]);
+    bounds[2] = std::min(uy[0], uy[1]); bounds[3] = std::max(uy[2], uy[3]);
+    return 0;
+}
+
+int orbref_is_in_frustum(int n, const float* pw, const float* normal, const float* min_dist, const float* max_dist,
+                         const float* rcw, const float* tcw, const float* ow, const float* kk, const float* bounds,
+                         float bf, float viewing_cos_limit, float log_scale_factor, int n_scale_levels,
+                         uint8_t* in_view, float* proj_x, float* proj_y, float* proj_xr, float* depth, int32_t* level, float* view_cos) {
+    if (n < 0) return -2;
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        in_view[i] = 0; proj_x[i] = -1.f; proj_y[i] = -1.f;
+        const float* P = pw + 3 * i;
+        float Pc[3];
+        for (int r = 0; r < 3; ++r) {                               // Matx33f * Matx31f: float accumulation from 0, k ascending
+            float s = 0.f;
+            for (int c = 0; c < 3; ++c) s += rcw[3 * r + c] * P[c];
+            Pc[r] = s + tcw[r];
+        }
+        double n2 = 0.0;                                            // cv::norm(Matx): double accumulation, sqrt in double
+        for (int c = 0; c < 3; ++c) n2 += (double)Pc[c] * (double)Pc[c];
+        const float Pc_dist = (float)std::sqrt(n2);
+        const float PcZ = Pc[2];
+        const float invz = 1.0f / PcZ;
+        if (PcZ < 0.0f) continue;
+        const float u = kk[0] * Pc[0] / Pc[2] + kk[2], v = kk[1] * Pc[1] / Pc[2] + kk[3];   // Pinhole.cpp:57-60
+        if (u < bounds[0] || u > bounds[1]) continue;
+        if (v < bounds[2] || v > bounds[3]) continue;
+        proj_x[i] = u; proj_y[i] = v;
+        const float maxD = 1.2f * max_dist[i], minD = 0.8f * min_dist[i];
+        float PO[3];
+        for (int c = 0; c < 3; ++c) PO[c] = P[c] - ow[c];
+        double d2 = 0.0;
+        for (int c = 0; c < 3; ++c) d2 += (double)PO[c] * (double)PO[c];
+        const float dist = (float)std::sqrt(d2);
+        if (dist < minD || dist > maxD) continue;
+        float dot = 0.f;
+        for (int c = 0; c < 3; ++c) dot += PO[c] * normal[3 * i + c];
+        const float vc = dot / dist;
+        if (vc < viewing_cos_limit) continue;
+        const float ratio = max_dist[i] / dist;                    // PredictScale (MapPoint.cc:725-740): float log, float divide
+        int ns = (int)std::ceil(std::log(ratio) / log_scale_factor);
+        if (ns < 0) ns = 0; else if (ns >= n_scale_levels) ns = n_scale_levels - 1;
+        in_view[i] = 1; proj_xr[i] = u - bf * invz; depth[i] = Pc_dist; level[i] = ns; view_cos[i] = vc;
+        ++cnt;
+    }
+    return cnt;
+}
+
 }  // extern "C"

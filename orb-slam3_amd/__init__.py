@@ -609,8 +609,66 @@ def _install_search():
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
     ORBmatcher.window_candidates = window_candidates
     ORBmatcher.ComputeStereoMatches = stereo_matches
+    _bind_frame_geometry(L, "orbm_")
+    for name, fn in _frame_geometry_methods("orbm_").items():
+        setattr(ORBmatcher, name, fn)
 
 
+def _bind_frame_geometry(L, prefix):
+    """argtypes of the undistort / image-bounds / frustum entry points (same argument lists on the product and the oracle,
+    except the leading handle + space of the product)."""
+    vp, f, i = C.c_void_p, C.c_float, C.c_int
+    lead = [vp, i] if prefix == "orbm_" else []
+    getattr(L, prefix + "undistort_keypoints").argtypes = lead + [vp, i, vp, vp, i, vp, vp]
+    getattr(L, prefix + "image_bounds").argtypes = ([vp] if prefix == "orbm_" else []) + [i, i, vp, vp, i, vp, vp]
+    getattr(L, prefix + "is_in_frustum").argtypes = lead + [i, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, f, f, i, vp, vp, vp, vp, vp, vp, vp]
+
+
+def _frame_geometry_methods(prefix):
+    def _lead(self, with_space=True):
+        return ([self.h, HOST] if with_space else [self.h]) if prefix == "orbm_" else []
+
+    def UndistortKeyPoints(self, kps, K, dist, newK=None):
+        """Frame::UndistortKeyPoints (Frame.cc:924-970).  K / newK = (fx, fy, cx, cy); dist = (k1, k2, p1, p2[, k3])."""
+        kps = np.ascontiguousarray(kps, KP_DTYPE); out = np.zeros(max(len(kps), 1), KP_DTYPE)
+        K = np.ascontiguousarray(K, np.float32); nk = K if newK is None else np.ascontiguousarray(newK, np.float32)
+        d = np.ascontiguousarray(dist, np.float32)
+        rc = getattr(self.L, prefix + "undistort_keypoints")(*_lead(self), _p(kps), len(kps), _p(K), _p(d), len(d), _p(nk), _p(out))
+        if rc < 0:
+            raise OrbError("undistort_keypoints failed with code %d" % rc)
+        return out[:len(kps)]
+
+    def ComputeImageBounds(self, cols, rows, K, dist, newK=None):
+        """Frame::ComputeImageBounds (Frame.cc:977-1021) -> (minX, maxX, minY, maxY)."""
+        K = np.ascontiguousarray(K, np.float32); nk = K if newK is None else np.ascontiguousarray(newK, np.float32)
+        d = np.ascontiguousarray(dist, np.float32); b = np.zeros(4, np.float32)
+        rc = getattr(self.L, prefix + "image_bounds")(*_lead(self, False), int(cols), int(rows), _p(K), _p(d), len(d), _p(nk), _p(b))
+        if rc < 0:
+            raise OrbError("image_bounds failed with code %d" % rc)
+        return b
+
+    def isInFrustum(self, Pw, normal, min_dist, max_dist, Rcw, tcw, Ow, K, bounds, bf, viewing_cos_limit, log_scale_factor, n_levels):
+        """Frame::isInFrustum for n map points (Frame.cc:603-671) -> dict of the MapPoint tracking members."""
+        Pw = np.ascontiguousarray(Pw, np.float32).reshape(-1, 3); n = len(Pw)
+        nm = np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+        mn = np.ascontiguousarray(min_dist, np.float32); mx = np.ascontiguousarray(max_dist, np.float32)
+        R = np.ascontiguousarray(Rcw, np.float32).reshape(9); t = np.ascontiguousarray(tcw, np.float32).reshape(3)
+        O = np.ascontiguousarray(Ow, np.float32).reshape(3); K = np.ascontiguousarray(K, np.float32); B = np.ascontiguousarray(bounds, np.float32)
+        out = {"in_view": np.zeros(max(n, 1), np.uint8), "proj_x": np.zeros(max(n, 1), np.float32), "proj_y": np.zeros(max(n, 1), np.float32),
+               "proj_xr": np.zeros(max(n, 1), np.float32), "depth": np.zeros(max(n, 1), np.float32), "level": np.full(max(n, 1), -1, np.int32),
+               "view_cos": np.zeros(max(n, 1), np.float32)}
+        rc = getattr(self.L, prefix + "is_in_frustum")(*_lead(self), n, _p(Pw), _p(nm), _p(mn), _p(mx), _p(R), _p(t), _p(O), _p(K), _p(B),
+                                                       float(bf), float(viewing_cos_limit), float(log_scale_factor), int(n_levels),
+                                                       _p(out["in_view"]), _p(out["proj_x"]), _p(out["proj_y"]), _p(out["proj_xr"]),
+                                                       _p(out["depth"]), _p(out["level"]), _p(out["view_cos"]))
+        if rc < 0:
+            raise OrbError("is_in_frustum failed with code %d" % rc)
+        return rc, {k: v[:n] for k, v in out.items()}
+
+    return {"UndistortKeyPoints": UndistortKeyPoints, "ComputeImageBounds": ComputeImageBounds, "isInFrustum": isInFrustum}
+
+
+EXPORTS += ["orbm_undistort_keypoints", "orbm_image_bounds", "orbm_is_in_frustum"]
 EXPORTS += ["orbm_grid_build", "orbm_window_candidates", "orbm_search_by_projection_frame", "orbm_search_by_projection_points",
             "orbm_search_for_initialization", "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_stereo_matches",
             "orbm_search_by_projection_kf", "orbm_search_by_bow_kf", "orbm_search_for_triangulation_legacy",

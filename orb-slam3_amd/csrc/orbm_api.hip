@@ -1194,4 +1194,87 @@ int orbm_stereo_matches(orbm_t* m, void* left, int frame_l, void* right, int fra
     return kept;
 }
 
+// ---- SURVEY 8(f).2 / 8(f).3 ------------------------------------------------------------------------------
+static bool fill_undist(UndistParams& P, const float* k, const float* dist, int ndist, const float* newk) {
+    for (double& d : P.k) d = 0.0;
+    for (int i = 0; i < ndist && i < 14; ++i) P.k[i] = (double)dist[i];
+    P.fx = k[0]; P.fy = k[1]; P.cx = k[2]; P.cy = k[3];
+    P.nfx = newk[0]; P.nfy = newk[1]; P.ncx = newk[2]; P.ncy = newk[3];
+    return ndist < 1 || dist[0] == 0.0f;                         // Frame.cc:928: first coefficient zero -> no undistortion
+}
+
+int orbm_undistort_keypoints(orbm_t* m, int space, const orbm_kp_t* kps, int n, const float* k, const float* dist, int ndist,
+                             const float* newk, orbm_kp_t* out) {
+    if (!m || n < 0 || !k || !newk || ndist < 0 || ndist > 14 || (ndist > 0 && !dist) || (n > 0 && (!kps || !out))) return ORBM_E_INVALID;
+    if (n == 0) return 0;
+    MHIPCHK(hipSetDevice(m->device));
+    UndistParams P;
+    const int pass = fill_undist(P, k, dist, ndist, newk) ? 1 : 0;
+    if (space == ORBM_DEVICE) {
+        hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, m->stream, (const KpIn*)kps, n, P, pass, (KpIn*)out);
+        MHIPCHK(hipGetLastError());
+        return n;
+    }
+    DevBuf di, dout;
+    UP(di, kps, sizeof(KpIn) * n); AL(dout, sizeof(KpIn) * n);
+    hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, m->stream, di.as<KpIn>(), n, P, pass, dout.as<KpIn>());
+    MHIPCHK(hipGetLastError());
+    MHIPCHK(hipStreamSynchronize(m->stream));
+    MHIPCHK(hipMemcpy(out, dout.p, sizeof(KpIn) * n, hipMemcpyDeviceToHost));
+    return n;
+}
+
+int orbm_image_bounds(orbm_t* m, int cols, int rows, const float* k, const float* dist, int ndist, const float* newk, float* bounds) {
+    if (!m || !k || !newk || !bounds || ndist < 0 || ndist > 14 || (ndist > 0 && !dist)) return ORBM_E_INVALID;
+    if (ndist < 1 || dist[0] == 0.0f) { bounds[0] = 0.f; bounds[1] = (float)cols; bounds[2] = 0.f; bounds[3] = (float)rows; return ORBM_OK; }
+    orbm_kp_t c[4], u[4];
+    memset(c, 0, sizeof(c));
+    c[1].x = (float)cols; c[2].y = (float)rows; c[3].x = (float)cols; c[3].y = (float)rows;
+    int rc = orbm_undistort_keypoints(m, ORBM_HOST, c, 4, k, dist, ndist, newk, u);
+    if (rc < 0) return rc;
+    bounds[0] = std::min(u[0].x, u[2].x); bounds[1] = std::max(u[1].x, u[3].x);      // Frame.cc:1005-1008
+    bounds[2] = std::min(u[0].y, u[1].y); bounds[3] = std::max(u[2].y, u[3].y);
+    return ORBM_OK;
+}
+
+int orbm_is_in_frustum(orbm_t* m, int space, int n, const float* pw, const float* normal, const float* min_dist, const float* max_dist,
+                       const float* rcw, const float* tcw, const float* ow, const float* k, const float* bounds,
+                       float bf, float viewing_cos_limit, float log_scale_factor, int n_scale_levels,
+                       uint8_t* in_view, float* proj_x, float* proj_y, float* proj_xr, float* depth, int32_t* level, float* view_cos) {
+    if (!m || n < 0 || !rcw || !tcw || !ow || !k || !bounds || n_scale_levels < 1) return ORBM_E_INVALID;
+    if (n == 0) return 0;
+    if (!pw || !normal || !min_dist || !max_dist || !in_view || !proj_x || !proj_y || !proj_xr || !depth || !level || !view_cos) return ORBM_E_INVALID;
+    MHIPCHK(hipSetDevice(m->device));
+    FrustumParams F;
+    memcpy(F.rcw, rcw, sizeof(F.rcw)); memcpy(F.tcw, tcw, sizeof(F.tcw)); memcpy(F.ow, ow, sizeof(F.ow));
+    memcpy(F.k, k, sizeof(F.k)); memcpy(F.bounds, bounds, sizeof(F.bounds));
+    F.bf = bf; F.cosLimit = viewing_cos_limit; F.logSF = log_scale_factor; F.nLevels = n_scale_levels;
+    const dim3 grid((n + 255) / 256), block(256);
+    if (space == ORBM_DEVICE) {
+        hipLaunchKernelGGL(k_frustum, grid, block, 0, m->stream, n, pw, normal, min_dist, max_dist, F, in_view, proj_x, proj_y, proj_xr,
+                           depth, level, view_cos);
+        MHIPCHK(hipGetLastError());
+        return 0;
+    }
+    DevBuf dp, dn, dmin, dmax, div, dx, dy, dxr, dd, dl, dvc;
+    UP(dp, pw, sizeof(float) * 3 * n); UP(dn, normal, sizeof(float) * 3 * n); UP(dmin, min_dist, sizeof(float) * n); UP(dmax, max_dist, sizeof(float) * n);
+    AL(div, n); AL(dx, sizeof(float) * n); AL(dy, sizeof(float) * n); AL(dxr, sizeof(float) * n); AL(dd, sizeof(float) * n);
+    AL(dl, sizeof(int) * n); AL(dvc, sizeof(float) * n);
+    // the reference leaves mTrackProjXR / mTrackDepth / mnTrackScaleLevel / mTrackViewCos untouched for rejected points:
+    // start from the caller's values
+    MHIPCHK(hipMemcpy(dxr.p, proj_xr, sizeof(float) * n, hipMemcpyHostToDevice)); MHIPCHK(hipMemcpy(dd.p, depth, sizeof(float) * n, hipMemcpyHostToDevice));
+    MHIPCHK(hipMemcpy(dl.p, level, sizeof(int) * n, hipMemcpyHostToDevice)); MHIPCHK(hipMemcpy(dvc.p, view_cos, sizeof(float) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_frustum, grid, block, 0, m->stream, n, dp.as<float>(), dn.as<float>(), dmin.as<float>(), dmax.as<float>(), F,
+                       div.as<uint8_t>(), dx.as<float>(), dy.as<float>(), dxr.as<float>(), dd.as<float>(), dl.as<int>(), dvc.as<float>());
+    MHIPCHK(hipGetLastError());
+    MHIPCHK(hipStreamSynchronize(m->stream));
+    MHIPCHK(hipMemcpy(in_view, div.p, n, hipMemcpyDeviceToHost)); MHIPCHK(hipMemcpy(proj_x, dx.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    MHIPCHK(hipMemcpy(proj_y, dy.p, sizeof(float) * n, hipMemcpyDeviceToHost)); MHIPCHK(hipMemcpy(proj_xr, dxr.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    MHIPCHK(hipMemcpy(depth, dd.p, sizeof(float) * n, hipMemcpyDeviceToHost)); MHIPCHK(hipMemcpy(level, dl.p, sizeof(int) * n, hipMemcpyDeviceToHost));
+    MHIPCHK(hipMemcpy(view_cos, dvc.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) cnt += in_view[i] ? 1 : 0;
+    return cnt;
+}
+
 }  // extern "C"

@@ -519,4 +519,87 @@ __global__ __launch_bounds__(256) void k_bow_transform(const uint8_t* __restrict
     node_id[i] = nid;
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_undistort: Frame::UndistortKeyPoints (Frame.cc:924-970) = cv::undistortPoints(K, D, R = I, P = newK), one thread per
+// keypoint, double arithmetic in OpenCV's operation order (5 fixed-point iterations; compiled without contraction).
+// ------------------------------------------------------------------------------------------------
+struct UndistParams { double k[14]; double fx, fy, cx, cy, nfx, nfy, ncx, ncy; };
+
+__device__ __forceinline__ void undistort_point(const UndistParams& P, double u, double v, float* ox, float* oy) {
+    const double ifx = 1.0 / P.fx, ify = 1.0 / P.fy;
+    double x = (u - P.cx) * ifx, y = (v - P.cy) * ify;
+    const double x0 = x, y0 = y;
+    const double* k = P.k;
+    for (int j = 0; j < 5; ++j) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        if (icdist < 0) { x = (u - P.cx) * ifx; y = (v - P.cy) * ify; break; }
+        const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+        const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = P.nfx * x + 0.0 * y + P.ncx, yy = 0.0 * x + P.nfy * y + P.ncy, ww = 1.0 / (0.0 * x + 0.0 * y + 1.0);
+    *ox = (float)(xx * ww); *oy = (float)(yy * ww);
+}
+
+__global__ __launch_bounds__(256) void k_undistort(const KpIn* __restrict__ in, int n, UndistParams P, int passthrough,
+                                                   KpIn* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    KpIn kp = in[i];
+    if (!passthrough) undistort_point(P, (double)kp.x, (double)kp.y, &kp.x, &kp.y);
+    out[i] = kp;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_frustum: Frame::isInFrustum (Nleft == -1, Frame.cc:603-671) + MapPoint::PredictScale (MapPoint.cc:725-740), one
+// thread per map point.  Float expressions in the reference's order (Matx products accumulate from 0 in float, cv::norm
+// accumulates in double); log(ratio) is evaluated in double and rounded to float (the host libm's logf is within 1 ulp of
+// that; the predicted level can differ only when log(ratio)/logScaleFactor is within an ulp of an integer).
+// ------------------------------------------------------------------------------------------------
+struct FrustumParams { float rcw[9], tcw[3], ow[3], k[4], bounds[4], bf, cosLimit, logSF; int nLevels; };
+
+__global__ __launch_bounds__(256) void k_frustum(int n, const float* __restrict__ pw, const float* __restrict__ normal,
+                                                 const float* __restrict__ minDist, const float* __restrict__ maxDist, FrustumParams F,
+                                                 uint8_t* inView, float* projX, float* projY, float* projXR, float* depth, int* level,
+                                                 float* viewCos) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    inView[i] = 0; projX[i] = -1.f; projY[i] = -1.f;
+    const float P0 = pw[3 * i], P1 = pw[3 * i + 1], P2 = pw[3 * i + 2];
+    float Pc[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float s = 0.f;
+        s += F.rcw[3 * r] * P0; s += F.rcw[3 * r + 1] * P1; s += F.rcw[3 * r + 2] * P2;
+        Pc[r] = s + F.tcw[r];
+    }
+    double n2 = 0.0;
+    n2 += (double)Pc[0] * (double)Pc[0]; n2 += (double)Pc[1] * (double)Pc[1]; n2 += (double)Pc[2] * (double)Pc[2];
+    const float PcDist = (float)sqrt(n2);
+    const float PcZ = Pc[2];
+    const float invz = 1.0f / PcZ;
+    if (PcZ < 0.0f) return;
+    const float u = F.k[0] * Pc[0] / Pc[2] + F.k[2], v = F.k[1] * Pc[1] / Pc[2] + F.k[3];
+    if (u < F.bounds[0] || u > F.bounds[1]) return;
+    if (v < F.bounds[2] || v > F.bounds[3]) return;
+    projX[i] = u; projY[i] = v;
+    const float maxD = 1.2f * maxDist[i], minD = 0.8f * minDist[i];
+    const float O0 = P0 - F.ow[0], O1 = P1 - F.ow[1], O2 = P2 - F.ow[2];
+    double d2 = 0.0;
+    d2 += (double)O0 * (double)O0; d2 += (double)O1 * (double)O1; d2 += (double)O2 * (double)O2;
+    const float dist = (float)sqrt(d2);
+    if (dist < minD || dist > maxD) return;
+    float dot = 0.f;
+    dot += O0 * normal[3 * i]; dot += O1 * normal[3 * i + 1]; dot += O2 * normal[3 * i + 2];
+    const float vc = dot / dist;
+    if (vc < F.cosLimit) return;
+    const float ratio = maxDist[i] / dist;
+    const float lg = (float)log((double)ratio);
+    int ns = (int)ceilf(lg / F.logSF);
+    if (ns < 0) ns = 0; else if (ns >= F.nLevels) ns = F.nLevels - 1;
+    inView[i] = 1; projXR[i] = u - F.bf * invz; depth[i] = PcDist; level[i] = ns; viewCos[i] = vc;
+}
+
 }  // namespace orbmk

@@ -181,3 +181,30 @@ def test_extract_degenerate_inputs(oracle, synth):
     assert n0 == n1 and m1 == 0 and m0 == n0
     assert np.array_equal(k1, k0[::-1]) and np.array_equal(d1, d0[::-1])
     assert set(np.unique(k0["octave"])) <= set(range(8)) and np.all(np.diff(k0["octave"]) >= 0)
+
+
+def test_undistort_and_frustum_known_answers(oracle, pkg):
+    """Hand-checkable cases of the 8(f).2 / 8(f).3 restatements."""
+    ref = oracle._oracle_matcher_class()()
+    K = [500.0, 500.0, 320.0, 240.0]
+    k = np.zeros(3, pkg.KP_DTYPE); k["x"] = [320.0, 0.0, 639.0]; k["y"] = [240.0, 0.0, 100.0]; k["octave"] = [0, 3, 7]
+    # zero first coefficient: copy (Frame.cc:928-932)
+    assert ref.UndistortKeyPoints(k, K, [0.0, 0.5, 0.1, 0.1]).tobytes() == k.tobytes()
+    # the principal point is a fixed point of any radial/tangential model
+    u = ref.UndistortKeyPoints(k, K, [-0.3, 0.1, 0.001, 0.002])
+    assert u["x"][0] == 320.0 and u["y"][0] == 240.0 and list(u["octave"]) == [0, 3, 7]
+    # barrel distortion (k1 < 0): undistorted corners move outwards
+    assert u["x"][1] < 0.0 and u["y"][1] < 0.0
+    b = ref.ComputeImageBounds(640, 480, K, [-0.3, 0.1, 0.0, 0.0])
+    assert b[0] < 0 and b[1] > 640 and b[2] < 0 and b[3] > 480
+    assert list(ref.ComputeImageBounds(640, 480, K, [0.0])) == [0.0, 640.0, 0.0, 480.0]
+    # frustum: a point on the optical axis at distance 4, seen head-on, maxDist 4*1.2^3 -> level ceil(3) = 3
+    lsf = float(np.log(np.float32(1.2)))
+    Pw = np.array([[0, 0, 4.0], [0, 0, -4.0], [100.0, 0, 4.0], [0, 0, 4.0], [0, 0, 4.0]], np.float32)
+    nm = np.array([[0, 0, 1.0], [0, 0, 1.0], [0, 0, 1.0], [0, 0, -1.0], [0, 0, 1.0]], np.float32)
+    mx = np.array([4.0 * 1.2 ** 3 * 0.999, 10, 10, 10, 3.0], np.float32); mn = np.full(5, 0.5, np.float32)
+    cnt, o = ref.isInFrustum(Pw, nm, mn, mx, np.eye(3), np.zeros(3), np.zeros(3), K, [0.0, 640.0, 0.0, 480.0], 40.0, 0.5, lsf, 8)
+    assert cnt == 1 and list(o["in_view"]) == [1, 0, 0, 0, 0]          # behind, outside, facing away, too far (4 > 1.2*3)
+    assert o["proj_x"][0] == 320.0 and o["proj_y"][0] == 240.0 and o["level"][0] == 3 and o["depth"][0] == 4.0
+    assert o["proj_xr"][0] == np.float32(320.0) - np.float32(40.0) * np.float32(0.25) and o["view_cos"][0] == 1.0
+    assert o["proj_x"][1] == -1.0 and o["proj_x"][2] == -1.0 and o["proj_x"][3] == 320.0   # bounds test passed before the later rejects
