@@ -1143,8 +1143,8 @@ __device__ __forceinline__ int reflect101(int p, int n) {   // valid for -n < p 
 
 // Streaming form: one wavefront owns a 256-pixel-wide column strip (4 px per lane, one dword) and walks
 // BL_R output rows downwards.  Per source row: ONE coalesced dword load per lane, neighbours' dwords through
-// __shfl (no LDS), horizontal 7-tap as two v_dot4_u32_u8 per pixel, then the vertical 7-tap over a rotating
-// 7-row register window.  Reflect-101 at the left/right image edge is done with v_perm selectors chosen on
+// DPP wave_shr/wave_shl (one VALU op, no LDS), horizontal 7-tap as two v_dot4_u32_u8 per pixel, then the vertical 7-tap
+// as four v_dot2_u32_u16 over a rotating 7-row register window of (previous row, row) sums.  Reflect-101 at the left/right image edge is done with v_perm selectors chosen on
 // the host from (width & 3); rows reflect through the row index.
 #define BL_R 32
 struct BlurTask { short level, g0, y0, pad; };            // g0 = first dword column of the strip, y0 = first output row
@@ -1205,10 +1205,10 @@ __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int 
             const int r = r0 + k;
             if (r < nrows) {
                 const u32 B = Bq[k], xtra = Xq[k];
-                u32 A = __shfl_up(B, 1);
+                u32 A = (u32)__builtin_amdgcn_update_dpp(0, (int)B, 0x138, 0xf, 0xf, false);       // wave_shr:1 = left neighbour's dword
                 if (lane == 0) A = xtra;
                 const u32 Bf = gc == gl ? __builtin_amdgcn_perm(A, B, selB) : B;
-                u32 C = __shfl_down(Bf, 1);
+                u32 C = (u32)__builtin_amdgcn_update_dpp(0, (int)Bf, 0x130, 0xf, 0xf, false);      // wave_shl:1 = right neighbour's dword
                 if (lane == 63) C = gc + 1 == gl ? __builtin_amdgcn_perm(B, xtra, selB) : xtra;
                 if (gc == gl) C = __builtin_amdgcn_perm(A, B, selC);
                 if (gc == 0) A = __builtin_amdgcn_perm(C, Bf, 0x01020304u);       // pixels -4..-1 <- 4,3,2,1
