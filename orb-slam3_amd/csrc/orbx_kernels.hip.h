@@ -1367,9 +1367,9 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
 #pragma unroll
         for (int it = 0; it < 6; ++it) bq[k][it] = 0;
         if (base + k < n) {                                     // wave-uniform
-            const int level = __builtin_amdgcn_readfirstlane(__shfl((int)w.level, 16 * k));
-            const int cx = __builtin_amdgcn_readfirstlane(__shfl((int)w.x, 16 * k));
-            const int cy = __builtin_amdgcn_readfirstlane(__shfl((int)w.y, 16 * k));
+            const int level = __builtin_amdgcn_readlane((int)w.level, 16 * k);
+            const int cx = __builtin_amdgcn_readlane((int)w.x, 16 * k);
+            const int cy = __builtin_amdgcn_readlane((int)w.y, 16 * k);
             int sp;
             const u8* im = level_ptr(g, l0, l0pitch, pyr, frame, level, &sp);
             const int xal = (cx - 15) & ~3;
@@ -1428,9 +1428,9 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
                         const int val = (int)((d >> (8 * b)) & 0xFF);
                         const bool in = (u < 0 ? -u : u) <= lim;
                         const int vv = in ? val : 0;
-                        m10 += u * vv; rowsum += vv;
+                        m10 += __mul24(u, vv); rowsum += vv;   // |u| <= 18, vv <= 255: 24-bit multiply (v_mul_lo_u32 is quarter rate)
                     }
-                    m01 += v * rowsum;
+                    m01 += __mul24(v, rowsum);                          // |v| <= 15, rowsum <= 4*255
                 }
             }
 #pragma unroll
@@ -1443,7 +1443,9 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ar = angle * factorPI;
-    const float a = (float)cos((double)ar), b = (float)sin((double)ar);
+    double sd, cd;
+    sincos((double)ar, &sd, &cd);                               // one range reduction for both (same kernels as sin / cos)
+    const float a = (float)cd, b = (float)sd;
     // ---- descriptor: 16 pairs per lane, sampled from the LDS copy of the keypoint's 37-row blurred patch (the patch
     // rows were requested together with the orientation rows: one global round trip per wave instead of two)
     const u8* pc = bpatch + ((threadIdx.x >> 6) * 4 + sub) * OD_PATCH + 18 * OD_PPITCH + bxoff;
@@ -1451,8 +1453,8 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const float4 pt = spat[q * 16 + sl];
-        const int o0 = __float2int_rn(pt.x * b + pt.y * a) * OD_PPITCH + __float2int_rn(pt.x * a - pt.y * b);
-        const int o1 = __float2int_rn(pt.z * b + pt.w * a) * OD_PPITCH + __float2int_rn(pt.z * a - pt.w * b);
+        const int o0 = __mul24(__float2int_rn(pt.x * b + pt.y * a), OD_PPITCH) + __float2int_rn(pt.x * a - pt.y * b);   // 24-bit multiplies: full rate
+        const int o1 = __mul24(__float2int_rn(pt.z * b + pt.w * a), OD_PPITCH) + __float2int_rn(pt.z * a - pt.w * b);
         t0[q] = valid ? pc[o0] : (u8)0;
         t1[q] = valid ? pc[o1] : (u8)0;
     }
