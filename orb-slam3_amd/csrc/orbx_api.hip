@@ -198,9 +198,9 @@ static int build_geometry(orbx* o, int w, int h) {
         D.selCap = std::max(D.N + 3, 4 * D.nIni) + 1;
         totalSel += D.selCap;
         maxN = std::max(maxN, std::max(D.N, 4 * D.nIni));
-        // blur tasks: one wavefront per (256-px column strip, BL_R-row block); right-edge reflect-101 selectors
+        // blur tasks: one wavefront per (248-px column strip, BL_R-row block); right-edge reflect-101 selectors
         for (int ty = 0; ty < D.h; ty += BL_R)
-            for (int gx = 0; gx * 4 < D.w; gx += 64) o->tiles.push_back(BlurTask{(short)l, (short)gx, (short)ty, 0});
+            for (int gx = 0; gx * 4 < D.w; gx += 62) o->tiles.push_back(BlurTask{(short)l, (short)gx, (short)ty, 0});   // 62 output dwords per wave
         {
             static const u32 kSelB[4] = {0x05060700u, 0x07000100u, 0x01020100u, 0x03020100u};   // k = (w-1)&3 valid bytes-1
             static const u32 kSelC[4] = {0x04040404u, 0x04040506u, 0x05060700u, 0x07000102u};

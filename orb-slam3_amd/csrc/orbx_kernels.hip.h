@@ -1141,7 +1141,7 @@ __device__ __forceinline__ int reflect101(int p, int n) {   // valid for -n < p 
     return p >= n ? 2 * n - 2 - p : p;
 }
 
-// Streaming form: one wavefront owns a 256-pixel-wide column strip (4 px per lane, one dword) and walks
+// Streaming form: one wavefront owns a 248-pixel-wide column strip (4 px per lane, one dword; lanes 0 and 63 are halo) and walks
 // BL_R output rows downwards.  Per source row: ONE coalesced dword load per lane, neighbours' dwords through
 // DPP wave_shr/wave_shl (one VALU op, no LDS), horizontal 7-tap as two v_dot4_u32_u8 per pixel, then the vertical 7-tap
 // as four v_dot2_u32_u16 over a rotating 7-row register window of (previous row, row) sums.  Reflect-101 at the left/right image edge is done with v_perm selectors chosen on
@@ -1167,7 +1167,9 @@ __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int 
     u8* dst = blr + (size_t)frame * g.pyrFrameBytes + L.off;
     const int w = L.w, h = L.h;
     const int gl = (w - 1) >> 2;                           // last dword column holding image pixels
-    const int gc = t.g0 + lane;
+    const int gc = t.g0 - 1 + lane;                        // lanes 0 and 63 are halo lanes: they load and filter, lanes 1..62 store
+    const int gcl = min(max(gc, 0), gl);                   // loads are unconditional on a clamped column (no exec juggling)
+    const bool isGl = gc == gl, isG0 = gc == 0;
     const u32 selB = bs.selB[t.level], selC = bs.selC[t.level];
     const u32 K1 = 18u | (34u << 8) | (48u << 16) | (56u << 24), K2 = 48u | (34u << 8) | (18u << 16);
     const int nrows = min(BL_R, h - t.y0) + 6;
@@ -1179,39 +1181,35 @@ __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int 
     const us2 KA = as_us2(18u | (34u << 16)), KB = as_us2(48u | (56u << 16)), KC = as_us2(48u | (34u << 16)), KD = as_us2(18u << 16);
     // software pipeline: the loads of row group n+1 are issued BEFORE the arithmetic and stores of group n, so
     // waiting for them never waits for younger stores (vmcnt retires in issue order on gfx9)
-    u32 Bn[7], Xn[7];
+    u32 Bn[7];
     auto fetch = [&](int r0) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             const int r = r0 + k;
-            Bn[k] = 0; Xn[k] = 0;
+            Bn[k] = 0;
             if (r < nrows) {
                 const int ys = reflect101(t.y0 - 3 + r, h);
-                const u32* row = (const u32*)(im + (size_t)ys * sp);
-                if (gc <= gl) Bn[k] = gload32(row + gc);
-                const int xg = lane == 0 ? gc - 1 : gc + 1;     // lane 0 fetches its left neighbour, lane 63 its right one
-                if ((lane == 0 || lane == 63) && xg >= 0 && xg <= gl) Xn[k] = gload32(row + xg);
+                Bn[k] = gload32((const u32*)(im + (size_t)ys * sp) + gcl);
             }
         }
     };
     fetch(0);
+    const bool doStore = lane >= 1 && lane <= 62 && gc <= gl;
     for (int r0 = 0; r0 < nrows; r0 += 7) {
-        u32 Bq[7], Xq[7];
+        u32 Bq[7];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) { Bq[k] = Bn[k]; Xq[k] = Xn[k]; }
+        for (int k = 0; k < 7; ++k) Bq[k] = Bn[k];
         fetch(r0 + 7);
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             const int r = r0 + k;
             if (r < nrows) {
-                const u32 B = Bq[k], xtra = Xq[k];
+                const u32 B = Bq[k];
                 u32 A = (u32)__builtin_amdgcn_update_dpp(0, (int)B, 0x138, 0xf, 0xf, false);       // wave_shr:1 = left neighbour's dword
-                if (lane == 0) A = xtra;
-                const u32 Bf = gc == gl ? __builtin_amdgcn_perm(A, B, selB) : B;
+                const u32 Bf = isGl ? __builtin_amdgcn_perm(A, B, selB) : B;                     // reflect the bytes beyond the last pixel
                 u32 C = (u32)__builtin_amdgcn_update_dpp(0, (int)Bf, 0x130, 0xf, 0xf, false);      // wave_shl:1 = right neighbour's dword
-                if (lane == 63) C = gc + 1 == gl ? __builtin_amdgcn_perm(B, xtra, selB) : xtra;
-                if (gc == gl) C = __builtin_amdgcn_perm(A, B, selC);
-                if (gc == 0) A = __builtin_amdgcn_perm(C, Bf, 0x01020304u);       // pixels -4..-1 <- 4,3,2,1
+                C = isGl ? __builtin_amdgcn_perm(A, B, selC) : C;                                 // the dword beyond the image
+                A = isG0 ? __builtin_amdgcn_perm(C, Bf, 0x01020304u) : A;                         // pixels -4..-1 <- 4,3,2,1
                 const u32 w1[4] = {__builtin_amdgcn_alignbyte(Bf, A, 1), __builtin_amdgcn_alignbyte(Bf, A, 2),
                                    __builtin_amdgcn_alignbyte(Bf, A, 3), Bf};
                 const u32 w2[4] = {__builtin_amdgcn_alignbyte(C, Bf, 1), __builtin_amdgcn_alignbyte(C, Bf, 2),
@@ -1234,7 +1232,7 @@ __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int 
                         acc[i] = __builtin_amdgcn_udot2(as_us2(Q[k][i]), KD, a, false);
                     }
                     const u32 packed = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u) | __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
-                    if (gc <= gl) *(u32*)(dst + (size_t)(t.y0 + r - 6) * L.pitch + gc * 4) = packed;
+                    if (doStore) *(u32*)(dst + (size_t)(t.y0 + r - 6) * L.pitch + gc * 4) = packed;
                 }
             }
         }
