@@ -199,8 +199,18 @@ static int build_geometry(orbx* o, int w, int h) {
         totalSel += D.selCap;
         maxN = std::max(maxN, std::max(D.N, 4 * D.nIni));
         // blur tasks: one wavefront per (248-px column strip, BL_R-row block); right-edge reflect-101 selectors
-        for (int ty = 0; ty < D.h; ty += BL_R)
-            for (int gx = 0; gx * 4 < D.w; gx += 62) o->tiles.push_back(BlurTask{(short)l, (short)gx, (short)ty, 0});   // 62 output dwords per wave
+        {   // strips of output dwords: the first stores from lane 0 (63 dwords), the others from lane 1 (62), and a strip whose
+            // lane 63 is the image's last dword stores that one too (k_blur2's doStore)
+            const int gl = (D.w - 1) >> 2;
+            for (int ty = 0; ty < D.h; ty += BL_R)
+                for (int g0 = 0; g0 <= gl;) {
+                    o->tiles.push_back(BlurTask{(short)l, (short)g0, (short)ty, 0});
+                    const int lead = g0 > 0 ? 1 : 0;
+                    int lastOut = g0 - lead + 62;
+                    if (g0 - lead + 63 == gl) lastOut = gl;
+                    g0 = lastOut + 1;
+                }
+        }
         {
             static const u32 kSelB[4] = {0x05060700u, 0x07000100u, 0x01020100u, 0x03020100u};   // k = (w-1)&3 valid bytes-1
             static const u32 kSelC[4] = {0x04040404u, 0x04040506u, 0x05060700u, 0x07000102u};

@@ -1167,7 +1167,10 @@ __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int 
     u8* dst = blr + (size_t)frame * g.pyrFrameBytes + L.off;
     const int w = L.w, h = L.h;
     const int gl = (w - 1) >> 2;                           // last dword column holding image pixels
-    const int gc = t.g0 - 1 + lane;                        // lanes 0 and 63 are halo lanes: they load and filter, lanes 1..62 store
+    // lanes 0 and 63 are halo lanes (they load and filter but do not store) -- except at the image's own left / right edge,
+    // where the neighbour is the reflection and the lane can store too (752 px = 63 + 62 + 63 dwords: exactly 3 strips)
+    const int lead = t.g0 > 0 ? 1 : 0;
+    const int gc = t.g0 - lead + lane;
     const int gcl = min(max(gc, 0), gl);                   // loads are unconditional on a clamped column (no exec juggling)
     const bool isGl = gc == gl, isG0 = gc == 0;
     const u32 selB = bs.selB[t.level], selC = bs.selC[t.level];
@@ -1194,7 +1197,7 @@ __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int 
         }
     };
     fetch(0);
-    const bool doStore = lane >= 1 && lane <= 62 && gc <= gl;
+    const bool doStore = lane >= lead && gc <= gl && (lane < 63 || gc == gl);
     for (int r0 = 0; r0 < nrows; r0 += 7) {
         u32 Bq[7];
 #pragma unroll
