@@ -532,10 +532,13 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
                         pq = q[e];
                         const int tx = pq & 511;
                         const u8* p = sc + (pq >> 9) * Pb + tx;
+                        // branch-free: all eight neighbours are read (the tile has a halo; a neighbour column outside the cell's
+                        // window may hold another cell's score, possibly mid-write -- it is masked to 0, never used)
                         const int s = p[0];
-                        keep = s > p[-Pb] && s > p[Pb];
-                        if (tx > cx0) keep = keep && s > p[-1] && s > p[-Pb - 1] && s > p[Pb - 1];
-                        if (tx < cx1 - 1) keep = keep && s > p[1] && s > p[-Pb + 1] && s > p[Pb + 1];
+                        const int ml = max(max((int)p[-1], (int)p[-Pb - 1]), (int)p[Pb - 1]);
+                        const int mr = max(max((int)p[1], (int)p[-Pb + 1]), (int)p[Pb + 1]);
+                        const int mv = max((int)p[-Pb], (int)p[Pb]);
+                        keep = s > max(mv, max(tx > cx0 ? ml : 0, tx < cx1 - 1 ? mr : 0));
                     }
                     const unsigned long long bal = __ballot(keep);
                     if (keep) q[n3 + __popcll(bal & lt)] = (u16)pq;
