@@ -421,8 +421,7 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
         if (cx1 > cx0 && vy1 > vy0) {
             // lane -> (row offset lr, 8-px column lc): ncol columns cover [cx0, cx1), rpi rows per wave-iteration
             const int c80 = cx0 >> 3, ncol = ((cx1 + 7) >> 3) - c80, nrow = vy1 - vy0;
-            int rpi = 1;
-            while ((rpi + 1) * ncol <= 64) ++rpi;
+            const int rpi = (int)(64.0f / (float)ncol);                  // floor(64 / ncol), ncol in 1..64 (exact: IEEE divide)
             int lr = (int)((float)lane / (float)ncol);
             if (lr * ncol > lane) --lr; else if ((lr + 1) * ncol <= lane) ++lr;
             const int lc = lane - lr * ncol;
@@ -433,7 +432,7 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
             u32 colmask = 0;
 #pragma unroll
             for (int bb = 0; bb < 8; ++bb)
-                if (tx8 + bb >= cx0 && tx8 + bb < cx1) colmask |= 8u << (4 * bb);
+                colmask |= (tx8 + bb >= cx0 && tx8 + bb < cx1 && lact) ? 8u << (4 * bb) : 0u;   // idle lanes: empty mask
             for (int pass = 0; pass < 2; ++pass) {
                 const int t = pass == 0 ? g.iniTh : g.minTh;
                 if (pass == 1 && g.minTh >= g.iniTh) break;               // a higher retry threshold cannot add corners
@@ -445,10 +444,12 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
 #else
                 for (int r0 = 0; r0 < nrow; r0 += rpi) {
 #endif
-                    const int r = r0 + lr;
+                    // no divergent branch around the test: lanes past the last row redo row nrow-1 and are masked out
+                    const bool rowok = r0 + lr < nrow;
+                    const int r = min(r0 + lr, nrow - 1);
                     u32 m = 0;
                     const int ty = vy0 + r;
-                    if (lact && r < nrow) {
+                    {
                         const u8* rowc = img + ty * Pb + tx8;
                         const uint2 Bq = *(const uint2*)rowc;
                         const u32 A = *(const u32*)(rowc - 4), Cw = *(const u32*)(rowc + 8);
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
                         }
                         const u32 Me = __builtin_amdgcn_perm(sg[2], sg[0], 0x07050301u);   // high bytes of px 0,2,4,6
                         const u32 Mo = __builtin_amdgcn_perm(sg[3], sg[1], 0x07050301u);   // px 1,3,5,7
-                        m = (((Me >> 4) & 0x08080808u) | (Mo & 0x80808080u)) & colmask;
+                        m = (((Me >> 4) & 0x08080808u) | (Mo & 0x80808080u)) & (rowok ? colmask : 0u);
                     }
                     // wave-inclusive prefix of popcount(m) (0..8) by a DPP scan, then each lane appends its own survivors
                     const int c = __popc(m);
