@@ -83,6 +83,7 @@ struct orbx {
     size_t capOvfList = 0;
     int f3QcapForce = 0;                                       // ORBX_FAST_QCAP: test knob, forces a small queue
     int8_t* dPattern = nullptr;
+    u32* dOdW = nullptr;                                       // IC_Angle byte weights (k_orient_desc2)
     size_t capL0 = 0, capPyr = 0, capCells = 0, capTiles = 0, capXt = 0, capYt = 0, capCandCnt = 0, capCandEnt = 0, capSel = 0;
     int lastBatch = 0;
     int l0pitch = 0, lastL0Pitch = 0;
@@ -427,7 +428,23 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
         if (hipMalloc((void**)&o->dL0Ptr, sizeof(u8*) * B) != hipSuccess || hipMalloc((void**)&o->dSelCnt, sizeof(u32) * 12 * B) != hipSuccess ||
             hipMalloc((void**)&o->dN, sizeof(int) * B) != hipSuccess || hipMalloc((void**)&o->dMono, sizeof(int) * B) != hipSuccess ||
             hipMalloc((void**)&o->dLap, sizeof(int) * 2 * B) != hipSuccess || hipMalloc((void**)&o->dErr, sizeof(int)) != hipSuccess ||
-            hipMalloc((void**)&o->dPattern, 1024) != hipSuccess || hipMalloc((void**)&o->dOvf, 2 * sizeof(u32)) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
+            hipMalloc((void**)&o->dPattern, 1024) != hipSuccess || hipMalloc((void**)&o->dOdW, sizeof(u32) * OD_WTAB) != hipSuccess || hipMalloc((void**)&o->dOvf, 2 * sizeof(u32)) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
+        {   // IC_Angle weights for v_dot4: entry [al][|v|][j] packs, for the 4 bytes of patch dword j of a row at distance |v| from
+            // the centre, (u + 16) where the pixel lies inside the disc (|u| <= umax[|v|]) and 0 elsewhere; u = 4j + b - 15 - al,
+            // al = (cx - 15) & 3 = where the patch starts inside its first aligned dword.  Row 16 is all zero (rows past the patch).
+            std::vector<u32> wt(OD_WTAB, 0u);
+            for (int al = 0; al < 4; ++al)
+                for (int va = 0; va < 16; ++va)
+                    for (int j = 0; j < 9; ++j) {
+                        u32 wv = 0;
+                        for (int b = 0; b < 4; ++b) {
+                            const int u = 4 * j + b - 15 - al;
+                            if (std::abs(u) <= o->umax.v[va]) wv |= (u32)(u + 16) << (8 * b);
+                        }
+                        wt[(al * 17 + va) * 9 + j] = wv;
+                    }
+            if (hipMemcpy(o->dOdW, wt.data(), sizeof(u32) * OD_WTAB, hipMemcpyHostToDevice) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMemcpy failed"); break; }
+        }
         if (hipMemcpy(o->dPattern, kPattern, 1024, hipMemcpyHostToDevice) != hipSuccess || hipMemset(o->dErr, 0, sizeof(int)) != hipSuccess || hipMemset(o->dOvf, 0, 2 * sizeof(u32)) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMemcpy failed"); break; }
         o->hL0Ptr.resize(B); o->hLap.resize(2 * B);
         rc = build_geometry(o, max_w, max_h);
@@ -443,7 +460,7 @@ void orbx_destroy(orbx_t* o) {
     if (o->stream) (void)hipStreamSynchronize(o->stream);
     if (o->stream2) (void)hipStreamSynchronize(o->stream2);
     void* ptrs[] = {o->dPyr, o->dBlur, o->dL0, (void*)o->dL0Ptr, o->dCells, o->dTiles, o->dStrips, o->dX4, o->dRzTasks, o->dXt, o->dYt, o->dCandCnt, o->dCandEnt,
-                    o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->dKps, o->dDesc, o->dWork, o->dN, o->dMono, o->dLap, o->dErr, o->dPattern, o->dOvf, o->dOvfList};
+                    o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->dKps, o->dDesc, o->dWork, o->dN, o->dMono, o->dLap, o->dErr, o->dPattern, o->dOvf, o->dOvfList, o->dOdW};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& set : o->evr) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     if (o->evDone) (void)hipEventDestroy(o->evDone);
@@ -578,7 +595,7 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
                            o->dWork, o->dN, o->dKps, o->dDesc, o->dPattern, o->umax);
     else
         hipLaunchKernelGGL(k_orient_desc2, dim3((g.kpCap + 15) / 16, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
-                           o->dWork, o->dN, o->dKps, o->dDesc, o->dPattern, o->umax);
+                           o->dWork, o->dN, o->dKps, o->dDesc, o->dPattern, o->dOdW);
     HIPCHK(hipEventRecord(o->ev[6], st));
     HIPCHK(hipGetLastError());
     o->lastBatch = nimg;

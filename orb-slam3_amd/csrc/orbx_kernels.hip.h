@@ -1337,15 +1337,18 @@ __global__ __launch_bounds__(256) void k_orient_desc(Geom g, const u8* const* l0
 //    The 512 pattern points sit in LDS as floats (staged once per workgroup).
 // ------------------------------------------------------------------------------------------------
 #define OD_PPITCH 40
+#define OD_WTAB (4 * 17 * 9)                               // IC_Angle weight table: [alignment][|v| (16 = zero row)][dword]
 #define OD_PATCH (37 * OD_PPITCH)
 __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
                                                       const u8* blr, const KpWork* __restrict__ work,
                                                       const int* __restrict__ nOut, KpOut* kps, u8* desc,
-                                                      const int8_t* __restrict__ pattern, Umax um) {
+                                                      const int8_t* __restrict__ pattern, const u32* __restrict__ odw) {
     __shared__ float4 spat[256];                               // (x0, y0, x1, y1) per pair
     __shared__ __attribute__((aligned(16))) u8 bpatch[16 * OD_PATCH];   // blurred 37 x 40-byte patch of each of the 16 keypoints
+    __shared__ u32 sW[OD_WTAB];                                // IC_Angle byte weights (see orbx_create)
     const int tid = threadIdx.x;
     {
+        for (int i = tid; i < OD_WTAB; i += 256) sW[i] = odw[i];
         const int raw = ((const int*)pattern)[tid];
         spat[tid] = make_float4((float)(int8_t)(raw & 0xFF), (float)(int8_t)((raw >> 8) & 0xFF),
                                 (float)(int8_t)((raw >> 16) & 0xFF), (float)(int8_t)((raw >> 24) & 0xFF));
@@ -1412,32 +1415,34 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int bxoff = w.x - ((w.x - 18) & ~3);                  // column of the keypoint inside its patch
+    // IC_Angle moments with v_dot4: per patch dword  S1 = sum (u+16)*I over the disc, S2 = sum I over the disc;
+    // m10 = S1 - 16*S2, m01 = sum over rows of v*S2.  The weights come from LDS ([alignment][|v|][dword]); the in-disc
+    // 0/1 bytes are the non-zero bytes of the weight word (u + 16 >= 1 inside the disc).
+    int tbl[5], vrow[5];
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        const int idx = it * 64 + lane;
+        const int r = (idx * 57) >> 9;
+        const int v = r - 15;
+        vrow[it] = v;
+        tbl[it] = min(v < 0 ? -v : v, 16) * 9 + (idx - r * 9);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (base + k < n) {
-            int m10 = 0, m01 = 0;
+            const u32* wk = sW + ((cxs[k] - 15) & 3) * (17 * 9);
+            u32 a1 = 0, a2 = 0;
+            int m01 = 0;
 #pragma unroll
             for (int it = 0; it < 5; ++it) {
-                const int idx = it * 64 + lane;
-                const int r = (idx * 57) >> 9;
-                const int j = idx - r * 9;
-                if (r < 31) {
-                    const int v = r - 15;
-                    const u32 d = dq[k][it];
-                    const int lim = um.v[v < 0 ? -v : v];
-                    const int u0 = xals[k] + 4 * j - cxs[k];
-                    int rowsum = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int u = u0 + b;
-                        const int val = (int)((d >> (8 * b)) & 0xFF);
-                        const bool in = (u < 0 ? -u : u) <= lim;
-                        const int vv = in ? val : 0;
-                        m10 += __mul24(u, vv); rowsum += vv;   // |u| <= 18, vv <= 255: 24-bit multiply (v_mul_lo_u32 is quarter rate)
-                    }
-                    m01 += __mul24(v, rowsum);                          // |v| <= 15, rowsum <= 4*255
-                }
+                const u32 w1 = wk[tbl[it]];
+                const u32 w2 = ((w1 + 0x7F7F7F7Fu) & 0x80808080u) >> 7;
+                a1 = __builtin_amdgcn_udot4(dq[k][it], w1, a1, false);
+                const u32 s2 = __builtin_amdgcn_udot4(dq[k][it], w2, 0u, false);
+                a2 += s2;
+                m01 += __mul24(vrow[it], (int)s2);
             }
+            int m10 = (int)a1 - 16 * (int)a2;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
             m10s[k] = m10; m01s[k] = m01;
