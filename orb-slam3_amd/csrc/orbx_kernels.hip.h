@@ -66,10 +66,20 @@ __device__ __forceinline__ u32 mad24(u32 a, u32 b, u32 c) {      // a*b + c on 2
 // Loads through an explicit global address space: pointers fetched from memory (the per-frame level-0 table)
 // are generic to the compiler, which would emit flat_load + conservative vmcnt(0)/lgkmcnt(0) waits.
 #if defined(__HIP_DEVICE_COMPILE__)
+// wave-uniform base + 32-bit per-lane byte offset: lets the compiler use the SGPR-base form of global_load (no 64-bit
+// per-lane address arithmetic)
+__device__ __forceinline__ u32 gload32u(const void* base, u32 off) {
+    return *(const __attribute__((address_space(1))) u32*)((const __attribute__((address_space(1))) u8*)base + off);
+}
+__device__ __forceinline__ void gstore32u(void* base, u32 off, u32 v) {
+    *(__attribute__((address_space(1))) u32*)((__attribute__((address_space(1))) u8*)base + off) = v;
+}
 __device__ __forceinline__ u32 gload32(const void* p) { return *(const __attribute__((address_space(1))) u32*)p; }
 __device__ __forceinline__ uint4 gload128(const void* p) { return *(const __attribute__((address_space(1))) uint4*)p; }
 __device__ __forceinline__ u8 gload8(const void* p) { return *(const __attribute__((address_space(1))) u8*)p; }
 #else
+__device__ __forceinline__ u32 gload32u(const void* base, u32 off) { return *(const u32*)((const u8*)base + off); }
+__device__ __forceinline__ void gstore32u(void* base, u32 off, u32 v) { *(u32*)((u8*)base + off) = v; }
 __device__ __forceinline__ u32 gload32(const void* p) { return *(const u32*)p; }
 __device__ __forceinline__ uint4 gload128(const void* p) { return *(const uint4*)p; }
 __device__ __forceinline__ u8 gload8(const void* p) { return *(const u8*)p; }
@@ -1196,7 +1206,7 @@ __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int 
             Bn[k] = 0;
             if (r < nrows) {
                 const int ys = reflect101(t.y0 - 3 + r, h);
-                Bn[k] = gload32((const u32*)(im + (size_t)ys * sp) + gcl);
+                Bn[k] = gload32u(im + (size_t)ys * sp, (u32)gcl * 4u);       // uniform row base + per-lane byte offset
             }
         }
     };
@@ -1239,7 +1249,7 @@ __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int 
                         acc[i] = __builtin_amdgcn_udot2(as_us2(Q[k][i]), KD, a, false);
                     }
                     const u32 packed = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u) | __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
-                    if (doStore) *(u32*)(dst + (size_t)(t.y0 + r - 6) * L.pitch + gc * 4) = packed;
+                    if (doStore) gstore32u(dst + (size_t)(t.y0 + r - 6) * L.pitch, (u32)gc * 4u, packed);
                 }
             }
         }
@@ -1387,7 +1397,7 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
                 const int idx = it * 64 + lane;
                 const int r = (idx * 57) >> 9;                  // idx / 9 for idx < 320
                 const int j = idx - r * 9;
-                if (r < 31) dq[k][it] = gload32(im + (size_t)(cy + r - 15) * sp + xal + 4 * j);
+                if (r < 31) dq[k][it] = gload32u(im, (u32)((cy + r - 15) * sp + xal + 4 * j));
             }
             // blurred patch: rows cy-18..cy+18, 10 aligned dwords from (cx-18)&~3
             const LevelDesc& Lk = g.lv[level];
@@ -1398,7 +1408,7 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
                 const int idx = it * 64 + lane;
                 const int r = (idx * 205) >> 11;                // idx / 10 for idx < 384
                 const int j = idx - r * 10;
-                if (r < 37) bq[k][it] = gload32(bl + (size_t)(cy + r - 18) * Lk.pitch + xalb + 4 * j);
+                if (r < 37) bq[k][it] = gload32u(bl, (u32)((cy + r - 18) * Lk.pitch + xalb + 4 * j));
             }
         }
     }
