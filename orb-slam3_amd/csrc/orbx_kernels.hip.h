@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, in
     u32 sh[4]; bool hiSel[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { sh[i] = (X.o[i] & 3u) * 8u; hiSel[i] = X.o[i] >= 4; }
-    const u8* colp = src + (size_t)X.bg * 4;
+    const u32 colo = (u32)X.bg * 4u;
     const bool ld1 = X.bg * 4 + 8 <= sp, ld2 = X.bg * 4 + 12 <= sp;     // taps beyond the row are never used; do not read them
     const int yend = min(y0 + RZ_R, D.h);
     const int sFirst = yt[D.rzy + y0].s;
@@ -180,10 +180,10 @@ __global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, in
     for (int j = 0; j < RZ_SRC; ++j) {
         d0[j] = d1[j] = d2[j] = 0;
         if (j < nsrc) {
-            const u8* p = colp + (size_t)(sFirst + j) * sp;
-            d0[j] = gload32(p);
-            if (ld1) d1[j] = gload32(p + 4);
-            if (ld2) d2[j] = gload32(p + 8);
+            const u8* rowp = src + (size_t)(sFirst + j) * sp;          // wave-uniform row base, per-lane 32-bit offset
+            d0[j] = gload32u(rowp, colo);
+            if (ld1) d1[j] = gload32u(rowp, colo + 4u);
+            if (ld2) d2[j] = gload32u(rowp, colo + 8u);
         }
     }
     int Hp[4] = {0, 0, 0, 0};
@@ -205,11 +205,12 @@ __global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, in
                     u32 packed = 0;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        int v = (((ty.a0 * (Hp[i] >> 4)) >> 16) + ((ty.a1 * (Hc[i] >> 4)) >> 16) + 2) >> 2;
+                        // taps <= 2048 and H >> 4 < 2^15: 24-bit multiplies (v_mul_lo_u32 is quarter rate)
+                        int v = ((__mul24(ty.a0, Hp[i] >> 4) >> 16) + (__mul24(ty.a1, Hc[i] >> 4) >> 16) + 2) >> 2;
                         v = min(max(v, 0), 255);
                         packed |= (u32)v << (8 * i);
                     }
-                    if (act) *(u32*)(dst + (size_t)dy * D.pitch + gcol * 4) = packed;
+                    if (act) gstore32u(dst + (size_t)dy * D.pitch, (u32)gcol * 4u, packed);
                     ++dy;
                 }
             }
@@ -1397,7 +1398,7 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
                 const int idx = it * 64 + lane;
                 const int r = (idx * 57) >> 9;                  // idx / 9 for idx < 320
                 const int j = idx - r * 9;
-                if (r < 31) dq[k][it] = gload32u(im, (u32)((cy + r - 15) * sp + xal + 4 * j));
+                if (r < 31) dq[k][it] = gload32u(im, (u32)(__mul24(cy + r - 15, sp) + xal + 4 * j));
             }
             // blurred patch: rows cy-18..cy+18, 10 aligned dwords from (cx-18)&~3
             const LevelDesc& Lk = g.lv[level];
@@ -1408,7 +1409,7 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
                 const int idx = it * 64 + lane;
                 const int r = (idx * 205) >> 11;                // idx / 10 for idx < 384
                 const int j = idx - r * 10;
-                if (r < 37) bq[k][it] = gload32u(bl, (u32)((cy + r - 18) * Lk.pitch + xalb + 4 * j));
+                if (r < 37) bq[k][it] = gload32u(bl, (u32)(__mul24(cy + r - 18, Lk.pitch) + xalb + 4 * j));
             }
         }
     }
