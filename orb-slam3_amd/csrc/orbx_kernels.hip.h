@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, in
                 const u32 lo = hiSel[i] ? d1[j] : d0[j], hi = hiSel[i] ? d2[j] : d1[j];
                 const u32 pair = __builtin_amdgcn_alignbit(hi, lo, sh[i]);
                 const us2 s2 = as_us2(__builtin_amdgcn_perm(0, pair, 0x0c010c00u));
-                Hc[i] = (int)__builtin_amdgcn_udot2(s2, as_us2(X.a[i]), 0u, false);
+                Hc[i] = (int)(__builtin_amdgcn_udot2(s2, as_us2(X.a[i]), 0u, false) >> 4);   // only (H >> 4) is ever used
             }
             if (dy < yend) {
                 const RzTab ty = yt[D.rzy + dy];
@@ -206,9 +206,9 @@ __global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, in
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         // taps <= 2048 and H >> 4 < 2^15: 24-bit multiplies (v_mul_lo_u32 is quarter rate)
-                        int v = ((__mul24(ty.a0, Hp[i] >> 4) >> 16) + (__mul24(ty.a1, Hc[i] >> 4) >> 16) + 2) >> 2;
-                        v = min(max(v, 0), 255);
-                        packed |= (u32)v << (8 * i);
+                        // each term is <= 1020, so (sum + 2) >> 2 <= 255: cv::resize's saturate_cast is the identity here
+                        const u32 v = (((u32)__mul24(ty.a0, Hp[i]) >> 16) + ((u32)__mul24(ty.a1, Hc[i]) >> 16) + 2u) >> 2;
+                        packed |= v << (8 * i);
                     }
                     if (act) gstore32u(dst + (size_t)dy * D.pitch, (u32)gcol * 4u, packed);
                     ++dy;
