@@ -96,6 +96,14 @@ int orbx_mean_timings(orbx_t*, float* ms8, int* nsamples);
  * reading the result buffers of the previous batch). */
 int orbx_stream_wait_results(orbx_t*, void* other_stream);
 int orbx_stream_wait_other(orbx_t*, void* other_stream);
+/* SURVEY 8(f).4 image ingest -- replaces cv::cvtColor(im, gray, COLOR_{RGB,BGR,RGBA,BGRA}2GRAY) in Tracking::GrabImage*
+ * (src/Tracking.cc:1264-1290, 1339-1348, 1393-1402).  nimg interleaved 8-bit colour images (src_space = ORBX_HOST | ORBX_DEVICE)
+ * are converted into the caller's DEVICE buffers dst[i] (dst_stride bytes per row; a multiple of 16 lets orbx_extract_batch*
+ * use them in place).  gray = (R*RY + G*GY + B*BY + half) >> coef_bits; coef_bits = 14: OpenCV 3.x coefficients
+ * (4899, 9617, 1868), 15: OpenCV 4.x (9798, 19235, 3735).  Enqueued on the extractor's stream (ordered before the next
+ * orbx_extract_batch_async). */
+int orbx_gray_from_color(orbx_t*, const uint8_t* const* src, int src_space, int nimg, int w, int h, int src_stride,
+                         int channels, int blue_first, int coef_bits, uint8_t* const* dst, int dst_stride);
 /* algorithmic bytes of the pyramid+FAST pass for one frame of the current geometry */
 int64_t orbx_algorithmic_bytes(const orbx_t*, int64_t* fused_lower_bound);
 void* orbx_stream(const orbx_t*);     /* hipStream_t the kernels are launched on */

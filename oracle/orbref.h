@@ -220,6 +220,14 @@ int orbref_is_in_frustum(int n, const float* pw, const float* normal, const floa
                          float bf, float viewing_cos_limit, float log_scale_factor, int n_scale_levels,
                          uint8_t* in_view, float* proj_x, float* proj_y, float* proj_xr, float* depth, int32_t* level, float* view_cos);
 
+/* SURVEY 8(f).4 image ingest: cv::cvtColor(src, gray, COLOR_{RGB,BGR,RGBA,BGRA}2GRAY) on 8-bit images
+ * (Tracking.cc:1264-1290, 1339-1348, 1393-1402).  OpenCV's fixed-point RGB2Gray<uchar> restated:
+ *   gray = (R*RY + G*GY + B*BY + (1 << (bits-1))) >> bits
+ * bits = 14: (RY, GY, BY) = (4899, 9617, 1868) -- OpenCV 3.x `yuv_shift`; bits = 15: (9798, 19235, 3735) -- OpenCV 4.x.
+ * Version (and IPP use) unpinned -> parity unpinned.  channels = 3 | 4, blue_first = 1 for BGR / BGRA. */
+int orbref_gray_from_color(const uint8_t* src, int w, int h, int src_stride, int channels, int blue_first, int coef_bits,
+                           uint8_t* dst, int dst_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -223,6 +223,19 @@ def _oracle_matcher_class():
     return OracleMatcher
 
 
+def gray_from_color(img, blue_first=False, coef_bits=15):
+    """cv::cvtColor(img, COLOR_{RGB,BGR,RGBA,BGRA}2GRAY) restated (orbref_gray_from_color)."""
+    L = lib()
+    L.orbref_gray_from_color.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, ch = img.shape
+    out = np.zeros((h, w), np.uint8)
+    rc = L.orbref_gray_from_color(_p(img), w, h, w * ch, ch, 1 if blue_first else 0, int(coef_bits), _p(out), w)
+    if rc:
+        raise RuntimeError("orbref_gray_from_color failed with code %d" % rc)
+    return out
+
+
 # ---- DBoW2 vocabulary transform (oracle side) ----
 class Vocabulary:
     def __init__(self, path):

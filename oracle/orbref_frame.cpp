@@ -970,4 +970,17 @@ int orbref_is_in_frustum(int n, const float* pw, const float* normal, const floa
     return cnt;
 }
 
+int orbref_gray_from_color(const uint8_t* src, int w, int h, int src_stride, int channels, int blue_first, int coef_bits,
+                           uint8_t* dst, int dst_stride) {
+    if (!src || !dst || w < 1 || h < 1 || (channels != 3 && channels != 4) || (coef_bits != 14 && coef_bits != 15)) return -2;
+    const int ry = coef_bits == 14 ? 4899 : 9798, gy = coef_bits == 14 ? 9617 : 19235, by = coef_bits == 14 ? 1868 : 3735;
+    const int c0 = blue_first ? by : ry, c2 = blue_first ? ry : by, half = 1 << (coef_bits - 1);
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* s = src + (size_t)y * src_stride;
+        uint8_t* d = dst + (size_t)y * dst_stride;
+        for (int x = 0; x < w; ++x, s += channels) d[x] = (uint8_t)((s[0] * c0 + s[1] * gy + s[2] * c2 + half) >> coef_bits);
+    }
+    return 0;
+}
+
 }  // extern "C"

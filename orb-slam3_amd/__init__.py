@@ -27,7 +27,7 @@ EXPORTS = [
     "orbx_create", "orbx_destroy", "orbx_last_error", "orbx_max_keypoints", "orbx_extract", "orbx_extract_batch",
     "orbx_extract_batch_async", "orbx_sync", "orbx_result_device", "orbx_result_fetch", "orbx_level_size",
     "orbx_level_image", "orbx_scale_tables", "orbx_features_per_level", "orbx_level_candidates",
-    "orbx_level_selected", "orbx_last_timings", "orbx_mean_timings", "orbx_stream_wait_results", "orbx_stream_wait_other", "orbx_algorithmic_bytes", "orbx_stream", "orbx_dev_alloc",
+    "orbx_level_selected", "orbx_last_timings", "orbx_mean_timings", "orbx_stream_wait_results", "orbx_stream_wait_other", "orbx_gray_from_color", "orbx_algorithmic_bytes", "orbx_stream", "orbx_dev_alloc",
     "orbx_dev_free", "orbx_memcpy_h2d", "orbx_memcpy_d2h", "orbx_device_count",
     # include/orbm.h
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_sync", "orbm_stream", "orbm_hamming",
@@ -75,6 +75,7 @@ def lib():
         L.orbx_mean_timings.argtypes = [vp, vp, i32p]
         L.orbx_stream_wait_results.argtypes = [vp, vp]
         L.orbx_stream_wait_other.argtypes = [vp, vp]
+        L.orbx_gray_from_color.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
         L.orbx_stream.restype = vp
         L.orbx_stream.argtypes = [vp]
         L.orbx_dev_alloc.restype = vp
@@ -219,6 +220,19 @@ class ORBextractor:
         _chk(self.L.orbx_extract_batch(self.h, ptrs, HOST, len(imgs), w, h, w, None if lap is None else _p(lap),
                                        _p(n_out), _p(m_out)), "orbx_extract_batch")
         return [self.fetch(i) for i in range(len(imgs))]
+
+    def gray_from_color(self, images, blue_first=False, coef_bits=15):
+        """cv::cvtColor(..., COLOR_*2GRAY) of equal-size HxWx{3,4} uint8 host images on the GPU (Tracking.cc:1264-1290).
+        Returns (DeviceBuffer, stride): the gray images back to back, usable by enqueue_device / extract."""
+        imgs = [np.ascontiguousarray(i, np.uint8) for i in images]
+        h, w, ch = imgs[0].shape
+        stride = (w + 63) // 64 * 64
+        buf = DeviceBuffer(stride * h * len(imgs))
+        srcs = (C.c_void_p * len(imgs))(*[i.ctypes.data for i in imgs])
+        dsts = (C.c_void_p * len(imgs))(*[buf.ptr + k * stride * h for k in range(len(imgs))])
+        _chk(self.L.orbx_gray_from_color(self.h, srcs, HOST, len(imgs), w, h, w * ch, ch, 1 if blue_first else 0, int(coef_bits), dsts, stride),
+             "orbx_gray_from_color")
+        return buf, stride
 
     def enqueue_device(self, dev_ptrs, w, h, stride, lapping=None):
         """dev_ptrs: ctypes array of device pointers; enqueue only (bench hot loop)."""

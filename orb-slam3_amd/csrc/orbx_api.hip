@@ -794,6 +794,45 @@ int orbx_stream_wait_other(orbx_t* o, void* other_stream) {
     return ORBX_OK;
 }
 
+int orbx_gray_from_color(orbx_t* o, const uint8_t* const* src, int src_space, int nimg, int w, int h, int src_stride,
+                         int channels, int blue_first, int coef_bits, uint8_t* const* dst, int dst_stride) {
+    if (!o || !src || !dst || nimg < 1 || w < 1 || h < 1 || (channels != 3 && channels != 4) || (coef_bits != 14 && coef_bits != 15) ||
+        src_stride < w * channels || dst_stride < w) return ORBX_E_INVALID;
+    for (int i = 0; i < nimg; ++i) if (!src[i] || !dst[i]) return ORBX_E_EMPTY;
+    HIPCHK(hipSetDevice(o->device));
+    const int ry = coef_bits == 14 ? 4899 : 9798, gy = coef_bits == 14 ? 9617 : 19235, by = coef_bits == 14 ? 1868 : 3735;
+    const int c0 = blue_first ? by : ry, c2 = blue_first ? ry : by;
+    hipStream_t st = o->stream;
+    // pointer tables (and, for host sources, the staged colour images) live in scratch freed after the stream has consumed them
+    const size_t imgBytes = (size_t)src_stride * h;
+    u8* stage = nullptr; const u8** dS = nullptr; u8** dD = nullptr;
+    std::vector<const u8*> hs(nimg);
+    int rc = ORBX_OK;
+    do {
+        if (hipMalloc((void**)&dS, sizeof(u8*) * nimg) != hipSuccess || hipMalloc((void**)&dD, sizeof(u8*) * nimg) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
+        if (src_space != ORBX_DEVICE) {
+            if (hipMalloc((void**)&stage, imgBytes * nimg) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
+            for (int i = 0; i < nimg && rc == ORBX_OK; ++i) {
+                if (hipMemcpyAsync(stage + imgBytes * i, src[i], imgBytes, hipMemcpyHostToDevice, st) != hipSuccess) { rc = ORBX_E_HIP; set_err("H2D failed"); }
+                hs[i] = stage + imgBytes * i;
+            }
+            if (rc) break;
+        } else {
+            for (int i = 0; i < nimg; ++i) hs[i] = src[i];
+        }
+        if (hipMemcpyAsync((void*)dS, hs.data(), sizeof(u8*) * nimg, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync((void*)dD, dst, sizeof(u8*) * nimg, hipMemcpyHostToDevice, st) != hipSuccess) { rc = ORBX_E_HIP; set_err("H2D failed"); break; }
+        hipLaunchKernelGGL(k_gray, dim3((w + 1023) / 1024, h, nimg), dim3(256), 0, st, dS, w, h, src_stride, channels, c0, gy, c2, coef_bits,
+                           dD, dst_stride);
+        if (hipGetLastError() != hipSuccess) { rc = ORBX_E_HIP; set_err("k_gray launch failed"); break; }
+    } while (0);
+    (void)hipStreamSynchronize(st);                              // scratch is freed below; the conversion itself is a one-pass stream kernel
+    if (stage) (void)hipFree(stage);
+    if (dS) (void)hipFree((void*)dS);
+    if (dD) (void)hipFree((void*)dD);
+    return rc;
+}
+
 int64_t orbx_algorithmic_bytes(const orbx_t* o, int64_t* fused_lower_bound) {
     if (!o) return ORBX_E_INVALID;
     if (fused_lower_bound) *fused_lower_bound = o->fusedBytes;

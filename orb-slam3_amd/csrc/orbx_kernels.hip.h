@@ -1493,4 +1493,41 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_gray: cv::cvtColor(..., COLOR_{RGB,BGR,RGBA,BGRA}2GRAY) for 8-bit images (Tracking.cc:1264-1290): OpenCV's fixed-point
+// RGB2Gray<uchar>, gray = (c0*C0 + c1*GY + c2*C2 + half) >> bits.  One thread makes 4 gray pixels (one dword store) from 12 /
+// 16 source bytes fetched as dwords when the row allows it.  Pure streaming: 4 or 5 bytes of HBM traffic per pixel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gray(const u8* const* srcs, int w, int h, int sstride, int ch,
+                                              int c0, int gy, int c2, int bits, u8* const* dsts, int dstride) {
+    const int frame = blockIdx.z;
+    const int y = blockIdx.y;
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x0 >= w || y >= h) return;
+    const u8* s = srcs[frame] + (size_t)y * sstride + (size_t)x0 * ch;
+    u8* d = dsts[frame] + (size_t)y * dstride + x0;
+    const int half = 1 << (bits - 1);
+    const int n = min(4, w - x0);
+    u32 px[4] = {0, 0, 0, 0};                                // low 24 bits: the three colour bytes of pixel i
+    if (n == 4 && (((size_t)s) & 3) == 0) {                  // aligned fast path: whole dwords
+        if (ch == 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) px[i] = gload32(s + 4 * i);
+        } else {
+            const u32 a = gload32(s), b = gload32(s + 4), c = gload32(s + 8);
+            px[0] = a; px[1] = __builtin_amdgcn_alignbyte(b, a, 3); px[2] = __builtin_amdgcn_alignbyte(c, b, 2); px[3] = c >> 8;
+        }
+    } else {
+        for (int i = 0; i < n; ++i) px[i] = (u32)gload8(s + i * ch) | ((u32)gload8(s + i * ch + 1) << 8) | ((u32)gload8(s + i * ch + 2) << 16);
+    }
+    u32 out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u32 v = (u32)(mad24(px[i] & 0xFFu, (u32)c0, mad24((px[i] >> 8) & 0xFFu, (u32)gy, mad24((px[i] >> 16) & 0xFFu, (u32)c2, (u32)half)))) >> bits;
+        out |= v << (8 * i);
+    }
+    if (n == 4 && (((size_t)d) & 3) == 0) *(u32*)d = out;
+    else for (int i = 0; i < n; ++i) d[i] = (u8)(out >> (8 * i));
+}
+
 }  // namespace orbxk

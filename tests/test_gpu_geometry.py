@@ -86,3 +86,41 @@ def test_frustum_feeds_search_by_projection(pkg, oracle):
     assert cnt == int(o["in_view"].sum())
     assert np.all(o["level"][o["in_view"] == 1] >= 0) and np.all(o["level"][o["in_view"] == 1] < 8)
     assert np.all(o["proj_x"][o["in_view"] == 1] >= 0.0)
+
+
+@pytest.mark.parametrize("ch,blue_first", [(3, False), (3, True), (4, False), (4, True)])
+@pytest.mark.parametrize("bits", [14, 15])
+@pytest.mark.parametrize("size", [(752, 480), (101, 37), (4, 3), (1, 1)])
+def test_gray_from_color_bit_exact(pkg, oracle, ch, blue_first, bits, size):
+    """SURVEY 8(f).4 ingest: cvtColor *2GRAY (Tracking.cc:1264-1290) on the GPU vs the restated OpenCV fixed point."""
+    w, h = size
+    rng = np.random.default_rng(w * 31 + h + ch)
+    imgs = [rng.integers(0, 256, (h, w, ch), dtype=np.uint8) for _ in range(2)]
+    imgs[1][..., :3] = np.array([[255, 255, 255]], np.uint8) if w > 1 else imgs[1][..., :3]      # saturation corner: white stays 255
+    ex = pkg.ORBextractor(500, max_size=(752, 480), max_batch=2)
+    try:
+        buf, stride = ex.gray_from_color(imgs, blue_first, bits)
+        for k, img in enumerate(imgs):
+            got = buf.download(np.uint8, stride * h, offset=k * stride * h).reshape(h, stride)[:, :w]
+            assert np.array_equal(got, oracle.gray_from_color(img, blue_first, bits))
+        if w > 1:
+            assert np.all(buf.download(np.uint8, stride * h, offset=stride * h).reshape(h, stride)[:, :w] == 255)
+    finally:
+        ex.close()
+
+
+def test_gray_then_extract_matches_gray_input(pkg, oracle, synth):
+    """The converted images are usable in place by the extractor (16-byte aligned rows)."""
+    import ctypes as C
+    g = synth.gen_image(752, 480, 5)
+    rgb = np.stack([g, g, g], axis=-1)                                   # R = G = B -> gray == the channel (coefficients sum to 1)
+    ex = pkg.ORBextractor(1000, max_size=(752, 480), max_batch=1)
+    try:
+        buf, stride = ex.gray_from_color([rgb], False, 15)
+        ex.enqueue_device((C.c_void_p * 1)(buf.ptr), 752, 480, stride, [(0, 1000)])
+        ex.sync()
+        mono, kps, desc = ex.fetch(0)
+        n_ref, kps_ref, desc_ref, mono_ref = oracle.Extractor(1000)(g, (0, 1000))
+        assert mono == mono_ref and kps.tobytes() == kps_ref.tobytes() and np.array_equal(desc, desc_ref)
+    finally:
+        ex.close()

@@ -208,3 +208,17 @@ def test_undistort_and_frustum_known_answers(oracle, pkg):
     assert o["proj_x"][0] == 320.0 and o["proj_y"][0] == 240.0 and o["level"][0] == 3 and o["depth"][0] == 4.0
     assert o["proj_xr"][0] == np.float32(320.0) - np.float32(40.0) * np.float32(0.25) and o["view_cos"][0] == 1.0
     assert o["proj_x"][1] == -1.0 and o["proj_x"][2] == -1.0 and o["proj_x"][3] == 320.0   # bounds test passed before the later rejects
+
+
+def test_gray_from_color_known_answers(oracle):
+    """OpenCV's RGB2Gray<uchar> fixed point: coefficients sum to 1 << bits, so gray levels map to themselves."""
+    for bits, (ry, gy, by) in ((14, (4899, 9617, 1868)), (15, (9798, 19235, 3735))):
+        assert ry + gy + by == 1 << bits
+        img = np.zeros((1, 4, 3), np.uint8)
+        img[0, 0] = (255, 255, 255); img[0, 1] = (255, 0, 0); img[0, 2] = (0, 255, 0); img[0, 3] = (0, 0, 255)
+        half = 1 << (bits - 1)
+        exp_rgb = [255, (255 * ry + half) >> bits, (255 * gy + half) >> bits, (255 * by + half) >> bits]
+        assert list(oracle.gray_from_color(img, False, bits)[0]) == exp_rgb
+        assert list(oracle.gray_from_color(img, True, bits)[0]) == [exp_rgb[0], exp_rgb[3], exp_rgb[2], exp_rgb[1]]
+        rgba = np.concatenate([img, np.full((1, 4, 1), 77, np.uint8)], axis=-1)
+        assert list(oracle.gray_from_color(rgba, False, bits)[0]) == exp_rgb       # alpha ignored
