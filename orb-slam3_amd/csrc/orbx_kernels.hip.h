@@ -428,6 +428,9 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
         const int cx0 = cell.x0 + 3 - st.xal, cx1 = cell.x0 + cell.cw - 3 - st.xal;   // valid columns (tile coords)
         const int vy0 = 3, vy1 = H - 3;
         int n3 = 0;
+#ifdef F3_ABL_NOAPPEND
+        u32 ablAcc = 0;
+#endif
         bool ovfl = false;                                                // survivors of the quick reject exceed the queue
         if (cx1 > cx0 && vy1 > vy0) {
             // lane -> (row offset lr, 8-px column lc): ncol columns cover [cx0, cx1), rpi rows per wave-iteration
@@ -492,6 +495,9 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
                         const u32 Mo = __builtin_amdgcn_perm(sg[3], sg[1], 0x07050301u);   // px 1,3,5,7
                         m = (((Me >> 4) & 0x08080808u) | (Mo & 0x80808080u)) & (rowok ? colmask : 0u);
                     }
+#ifdef F3_ABL_NOAPPEND
+                    ablAcc |= m; continue;
+#endif
                     // wave-inclusive prefix of popcount(m) (0..8) by a DPP scan, then each lane appends its own survivors
                     const int c = __popc(m);
                     int sc_ = c;
@@ -578,6 +584,9 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
                 else atomicExch(err, 1);
             }
         }
+#ifdef F3_ABL_NOAPPEND
+        if (ablAcc == 0x12345u) sc[0] = 1;
+#endif
         if (lane == 0) candCnt[(size_t)frame * g.totalCells + cell.cnt] = (u32)n3;
     }
 }
