@@ -254,6 +254,40 @@ __device__ __forceinline__ int fast_score16(const u8* t, int p) {
     return max(v - amin, bmax - v) - 1;
 }
 
+// Two pixels per lane: the same network on packed 16-bit halves (v_pk_min/max_u16 have no 3-input form, so 47 packed ops
+// per side serve two pixels: 47 per pixel against 72).  The ring bytes of pixel A land in the low halves, those of
+// pixel B in the high halves (ds_read_u8_d16 / _d16_hi).  Returns the two scores as signed 16-bit halves.
+typedef short ss2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ss2 fast_score16x2(const u8* ta, const u8* tb, int p) {
+    // (an 8-byte-per-row variant with unaligned ds_read_b64 -- 7 LDS reads per pixel instead of 17 -- is bit-exact but 1.7x
+    // slower on gfx950: unaligned LDS reads are split.  The scattered byte reads bound this phase, not the min/max network.)
+    const u8* a0 = ta - 3 * p - 3; const u8* b0 = tb - 3 * p - 3;
+    const u8 *a1 = a0 + p, *a2 = a1 + p, *a3 = a2 + p, *a4 = a3 + p, *a5 = a4 + p, *a6 = a5 + p;
+    const u8 *b1 = b0 + p, *b2 = b1 + p, *b3 = b2 + p, *b4 = b3 + p, *b5 = b4 + p, *b6 = b5 + p;
+#define F2(ra, rb, o) us2{(u16)(ra)[o], (u16)(rb)[o]}
+    us2 r[16];
+    r[0] = F2(a6, b6, 3);   r[1] = F2(a6, b6, 4);   r[2] = F2(a5, b5, 5);   r[3] = F2(a4, b4, 6);
+    r[4] = F2(a3, b3, 6);   r[5] = F2(a2, b2, 6);   r[6] = F2(a1, b1, 5);   r[7] = F2(a0, b0, 4);
+    r[8] = F2(a0, b0, 3);   r[9] = F2(a0, b0, 2);   r[10] = F2(a1, b1, 1);  r[11] = F2(a2, b2, 0);
+    r[12] = F2(a3, b3, 0);  r[13] = F2(a4, b4, 0);  r[14] = F2(a5, b5, 1);  r[15] = F2(a6, b6, 2);
+    const us2 v = F2(a3, b3, 3);
+#undef F2
+    us2 m2[8], M2[8], m4[8], M4[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { m2[j] = pkmin(r[2 * j], r[2 * j + 1]); M2[j] = pkmax(r[2 * j], r[2 * j + 1]); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { m4[j] = pkmin(m2[j], m2[(j + 1) & 7]); M4[j] = pkmax(M2[j], M2[(j + 1) & 7]); }
+    us2 bmax = us2{0, 0}, amin = us2{255, 255};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const us2 a = r[(2 * j + 15) & 15], c = r[(2 * j + 8) & 15];
+        bmax = pkmax(bmax, pkmin(pkmin(m4[j], m4[(j + 2) & 7]), pkmax(a, c)));
+        amin = pkmin(amin, pkmax(pkmax(M4[j], M4[(j + 2) & 7]), pkmin(a, c)));
+    }
+    const ss2 d1 = __builtin_bit_cast(ss2, v - amin), d2 = __builtin_bit_cast(ss2, bmax - v);   // |.| <= 255: exact as signed 16-bit
+    return __builtin_elementwise_max(d1, d2) - ss2{1, 1};
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_fast: one workgroup per FAST cell (the sub-image the reference hands to cv::FAST).
 // LDS: the (cw x ch) byte tile and the score tile.  Non-max suppression never looks across the cell
@@ -523,22 +557,23 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
 #ifdef F3_ABL_NOSCORE
                 n1 = 0;
 #endif
-                // ---- exact score; keep pixels with S >= t (in place)
+                // ---- exact score, two survivors per lane (entries 2*lane and 2*lane+1 keep the queue order); keep S >= t in place
                 int n2 = 0;
-                for (int e0 = 0; e0 < n1; e0 += 64) {
-                    const int e = e0 + lane;
-                    bool f = false;
-                    int pq = 0;
-                    if (e < n1) {
-                        pq = q[e];
-                        const int px = (pq >> 9) * Pb + (pq & 511);
-                        const int s = fast_score16(img + px, Pb);
-                        f = s >= t;
-                        if (f) sc[px] = (u8)s;
-                    }
-                    const unsigned long long bal = __ballot(f);
-                    if (f) q[n2 + __popcll(bal & lt)] = (u16)pq;
-                    n2 += __popcll(bal);
+                for (int e0 = 0; e0 < n1; e0 += 128) {
+                    const int eA = e0 + 2 * lane, eB = eA + 1;
+                    const u32 both = *(const u32*)(q + min(eA, (n1 - 1) & ~1));      // entries eA, eB in one aligned 32-bit read
+                    const int pqA = (int)(both & 0xFFFFu), pqB = (int)(both >> 16);
+                    const int pxA = (pqA >> 9) * Pb + (pqA & 511);
+                    const int pxB = eB < n1 ? (pqB >> 9) * Pb + (pqB & 511) : pxA;    // odd tail: score A twice, B is masked out
+                    const ss2 sv = fast_score16x2(img + pxA, img + pxB, Pb);
+                    const bool fA = eA < n1 && sv.x >= t, fB = eB < n1 && sv.y >= t;
+                    if (fA) sc[pxA] = (u8)sv.x;
+                    if (fB) sc[pxB] = (u8)sv.y;
+                    const unsigned long long balA = __ballot(fA), balB = __ballot(fB);
+                    const int posA = n2 + __popcll(balA & lt) + __popcll(balB & lt);
+                    if (fA) q[posA] = (u16)pqA;
+                    if (fB) q[posA + (fA ? 1 : 0)] = (u16)pqB;
+                    n2 += __popcll(balA) + __popcll(balB);
                 }
                 // ---- strict 3x3 maxima inside the cell window (in place)
                 n3 = 0;
