@@ -158,7 +158,6 @@ __global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, in
     const int g0 = __builtin_amdgcn_readfirstlane(t.g0), y0 = __builtin_amdgcn_readfirstlane(t.y0);
     const int frame = blockIdx.y;
     const LevelDesc& D = g.lv[level];
-    const LevelDesc& S = g.lv[level - 1];
     int sp;
     const u8* src = level_ptr(g, l0, l0pitch, pyr, frame, level - 1, &sp);
     u8* dst = pyr + (size_t)frame * g.pyrFrameBytes + D.off;

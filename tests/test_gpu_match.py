@@ -53,3 +53,14 @@ def test_scalar_helpers(pkg, oracle):
     for _ in range(20):
         c = rng.integers(0, 12, 30).astype(np.int32)
         assert np.array_equal(pkg.ORBmatcher.ComputeThreeMaxima(c), oracle.three_maxima(c))
+
+
+@pytest.mark.gpu
+def test_knn2_rejects_train_sets_beyond_the_packed_index_range(pkg):
+    """k_knn2 packs (distance << 22 | train index) into one key: 2^22 train descriptors per pair is the documented limit."""
+    import ctypes as C
+    m = pkg.ORBmatcher()
+    one = pkg.DeviceBuffer(64)
+    rc = m.L.orbm_knn2_batch_async(m.h, one.ptr, 1, one.ptr, one.ptr, 1 << 22, one.ptr, 1, 1 << 22, one.ptr, one.ptr)
+    assert rc < 0
+    assert b"2^22" in m.L.orbm_last_error()
