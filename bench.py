@@ -199,6 +199,22 @@ def main():
             traffic = None
         stage = {k: float(np.mean([tm[k] for tm, _ in t_all])) for k in t_all[0][0]}
         stage["match_" + args.match] = mt.timing_ms()
+        # secondary denominator: the device-to-device copy rate this GPU actually reaches, measured here with a
+        # 1 GiB torch copy (read + write bytes / time), outside the timed region
+        copy_gbs = None
+        try:
+            n = 1 << 30
+            a = torch.empty(n, dtype=torch.uint8, device=cdev); b = torch.empty_like(a)
+            b.copy_(a); torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                b.copy_(a)
+            e1.record(); torch.cuda.synchronize()
+            copy_gbs = 2.0 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del a, b
+        except Exception:
+            copy_gbs = None
         out = {
             "metric": "ORB extract+match frames/sec @752x480, 1000 feat",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -209,10 +225,11 @@ def main():
                                    % (W, H, args.nfeatures, B, "Frame grid build and SearchByProjection window match (th=15) of every keypoint"
                                       if args.match == "window" else "dense 2-NN Hamming match"),
                        "frames_per_step_per_gpu": B, "handles_in_flight": NH, "keypoints_last_batch": int(total_kp.item())},
-            "roofline": {"bound": "hbm", "kernel": "pyramid+FAST pass (k_resize2 x7 on stream 2 + k_fast3 x2 on stream 1; wall span by HIP events)",
+            "roofline": {"bound": "hbm", "kernel": "pyramid+FAST pass (k_resize2 x7 on stream 2 + k_fast3 x3 and k_fast_fix on stream 1; wall span by HIP events)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg * (B / NH), "frames_per_launch": B / NH, "algorithmic_bytes_per_frame": alg, "fused_lower_bound_per_frame": fused,
-                         "launch_ms": pf_ms},
+                         "launch_ms": pf_ms, "measured_copy_peak_GBps": copy_gbs,
+                         "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None},
             "stage_ms_per_step": stage,
         }
         if world == 1 and args.cpu_sample > 0:
