@@ -238,20 +238,31 @@ static int build_geometry(orbx* o, int w, int h) {
                 fy -= sy;
                 o->yt.push_back(RzTab{sy, sat((1.f - fy) * 2048.f), sat(fy * 2048.f)});
             }
-            // per-dword tables of the streaming kernel; it needs every tap pair inside 12 loaded bytes (offset <= 7)
+            // per-dword tables of the streaming kernel: it loads 8 bytes from the first tap, so every tap pair must start
+            // within 6 bytes of it (true for scale factors up to 1.5; otherwise the level uses k_resize)
             while (o->x4.size() * 4 < (size_t)D.rzx) o->x4.push_back(RzX4{});
-            bool ok = (D.rzx % 4) == 0;
+            bool ok = (D.rzx % 4) == 0 && S.w >= 8;
             for (int gx = 0; gx * 4 < D.w && ok; ++gx) {
                 RzX4 e{};
-                const int first = o->xt[D.rzx + gx * 4].s;
-                e.bg = first >> 2;
+                int sx[4];
                 for (int i = 0; i < 4; ++i) {
                     const int dx = std::min(gx * 4 + i, D.w - 1);
                     const RzTab& tb = o->xt[D.rzx + dx];
-                    const int off = tb.s - e.bg * 4;
-                    if (off < 0 || off > 7 || tb.a0 < 0 || tb.a1 < 0) { ok = false; break; }
+                    if (tb.s < 0 || tb.a0 < 0 || tb.a1 < 0) { ok = false; break; }
+                    if (tb.s + 1 < S.w) {
+                        sx[i] = tb.s;
+                        e.a[i] = (u32)(unsigned short)tb.a0 | ((u32)(unsigned short)tb.a1 << 16);
+                    } else {                                           // clamped last column (a1 == 0): pair (w-2, w-1), weight on the second
+                        sx[i] = tb.s - 1;
+                        e.a[i] = (u32)(unsigned short)tb.a0 << 16;
+                    }
+                }
+                if (!ok) break;
+                e.bs = *std::min_element(sx, sx + 4);
+                for (int i = 0; i < 4; ++i) {
+                    const int off = sx[i] - e.bs;
+                    if (off < 0 || off > 6) { ok = false; break; }
                     e.o[i] = (u8)off;
-                    e.a[i] = (u32)(unsigned short)tb.a0 | ((u32)(unsigned short)tb.a1 << 16);
                 }
                 o->x4.push_back(e);
             }

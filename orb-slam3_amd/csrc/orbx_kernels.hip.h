@@ -74,11 +74,17 @@ __device__ __forceinline__ u32 gload32u(const void* base, u32 off) {
 __device__ __forceinline__ void gstore32u(void* base, u32 off, u32 v) {
     *(__attribute__((address_space(1))) u32*)((__attribute__((address_space(1))) u8*)base + off) = v;
 }
+__device__ __forceinline__ uint2 gload64u_unaligned(const void* base, u32 off) {   // 8 bytes at ANY byte offset (global memory: unaligned mode)
+    typedef unsigned long long __attribute__((aligned(1))) u64a1;
+    const unsigned long long v = *(const __attribute__((address_space(1))) u64a1*)((const __attribute__((address_space(1))) u8*)base + off);
+    return make_uint2((u32)v, (u32)(v >> 32));
+}
 __device__ __forceinline__ u32 gload32(const void* p) { return *(const __attribute__((address_space(1))) u32*)p; }
 __device__ __forceinline__ uint4 gload128(const void* p) { return *(const __attribute__((address_space(1))) uint4*)p; }
 __device__ __forceinline__ u8 gload8(const void* p) { return *(const __attribute__((address_space(1))) u8*)p; }
 #else
 __device__ __forceinline__ u32 gload32u(const void* base, u32 off) { return *(const u32*)((const u8*)base + off); }
+__device__ __forceinline__ uint2 gload64u_unaligned(const void* base, u32 off) { uint2 r; __builtin_memcpy(&r, (const u8*)base + off, 8); return r; }
 __device__ __forceinline__ void gstore32u(void* base, u32 off, u32 v) { *(u32*)((u8*)base + off) = v; }
 __device__ __forceinline__ u32 gload32(const void* p) { return *(const u32*)p; }
 __device__ __forceinline__ uint4 gload128(const void* p) { return *(const uint4*)p; }
@@ -137,14 +143,15 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, const u8* const* l0, int
 // ------------------------------------------------------------------------------------------------
 // k_resize2: streaming form of the same arithmetic.  One wavefront owns 256 destination pixels of a row
 // (4 px per lane, stored as one dword) and walks RZ_R destination rows downwards.  Per SOURCE row a lane
-// loads 12 contiguous bytes (3 dwords) that cover its 4 tap pairs; the pair for pixel i is cut out with
-// v_alignbit at a per-lane constant offset and reduced with one v_dot2_u32_u16 against (a0,a1).  The
+// loads the 8 bytes that start at its first tap (one unaligned global_load_dwordx2 from the wave-uniform row base:
+// the four tap pairs of a lane span < 8 bytes for scale factors up to 1.5); the pair of pixel i is picked and widened
+// by ONE v_perm with a per-lane selector and reduced with one v_dot2_u32_u16 against (a0,a1).  The
 // horizontal result of source row sy+1 is reused as row sy of the next destination row (the reference's
 // cv::resize keeps the same two-row cache).  Row taps come from the scalar unit (wave-uniform).
 // ------------------------------------------------------------------------------------------------
 #define RZ_R 8
 #define RZ_SRC 12                                          // source rows one task may touch (host checks)
-struct RzX4 { int bg; u8 o[4]; u32 a[4]; };                // per destination dword: base source dword, byte offsets, (a0 | a1<<16)
+struct RzX4 { int bs; u8 o[4]; u32 a[4]; };                // per destination dword: byte offset of the first tap, tap offsets from it (<= 6), (a0 | a1<<16)
 struct RzTask { short level, g0, y0, pad; };
 
 __global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, int l0pitch, u8* pyr,
@@ -165,25 +172,22 @@ __global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, in
     const int ndw = (D.w + 3) >> 2;
     const bool act = gcol < ndw;
     const RzX4 X = x4[D.rzx / 4 + (act ? gcol : ndw - 1)];   // rzx is the level's offset in pixels; the x4 table is per dword
-    u32 sh[4]; bool hiSel[4];
+    // the 8-byte window never leaves the row's pitch: near the right edge it slides left and the selectors follow
+    const int bsc = min(X.bs, sp - 8);
+    const u32 delta = (u32)(X.bs - bsc);                      // 0..6; every tap index + delta stays <= 7 (taps lie inside the row)
+    u32 sel[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { sh[i] = (X.o[i] & 3u) * 8u; hiSel[i] = X.o[i] >= 4; }
-    const u32 colo = (u32)X.bg * 4u;
-    const bool ld1 = X.bg * 4 + 8 <= sp, ld2 = X.bg * 4 + 12 <= sp;     // taps beyond the row are never used; do not read them
+    for (int i = 0; i < 4; ++i) sel[i] = 0x0c000c00u | ((u32)X.o[i] + delta) | (((u32)X.o[i] + delta + 1u) << 16);
+    const u32 colo = (u32)bsc;
     const int yend = min(y0 + RZ_R, D.h);
     const int sFirst = yt[D.rzy + y0].s;
     const int nsrc = yt[D.rzy + yend - 1].s + 2 - sFirst;               // host guarantees 0 <= s, s+1 < S.h, nsrc <= RZ_SRC
     // all source rows of the task in flight before any arithmetic
-    u32 d0[RZ_SRC], d1[RZ_SRC], d2[RZ_SRC];
+    uint2 d[RZ_SRC];
 #pragma unroll
     for (int j = 0; j < RZ_SRC; ++j) {
-        d0[j] = d1[j] = d2[j] = 0;
-        if (j < nsrc) {
-            const u8* rowp = src + (size_t)(sFirst + j) * sp;          // wave-uniform row base, per-lane 32-bit offset
-            d0[j] = gload32u(rowp, colo);
-            if (ld1) d1[j] = gload32u(rowp, colo + 4u);
-            if (ld2) d2[j] = gload32u(rowp, colo + 8u);
-        }
+        d[j] = make_uint2(0, 0);
+        if (j < nsrc) d[j] = gload64u_unaligned(src + (size_t)(sFirst + j) * sp, colo);   // wave-uniform row base, per-lane offset
     }
     int Hp[4] = {0, 0, 0, 0};
     int dy = y0;
@@ -193,9 +197,7 @@ __global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, in
             int Hc[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const u32 lo = hiSel[i] ? d1[j] : d0[j], hi = hiSel[i] ? d2[j] : d1[j];
-                const u32 pair = __builtin_amdgcn_alignbit(hi, lo, sh[i]);
-                const us2 s2 = as_us2(__builtin_amdgcn_perm(0, pair, 0x0c010c00u));
+                const us2 s2 = as_us2(__builtin_amdgcn_perm(d[j].y, d[j].x, sel[i]));      // (byte o, byte o+1) as a u16 pair
                 Hc[i] = (int)(__builtin_amdgcn_udot2(s2, as_us2(X.a[i]), 0u, false) >> 4);   // only (H >> 4) is ever used
             }
             if (dy < yend) {
