@@ -471,17 +471,19 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
             // lane -> (row offset lr, 8-px column lc): ncol columns cover [cx0, cx1), rpi rows per wave-iteration
             const int c80 = cx0 >> 3, ncol = ((cx1 + 7) >> 3) - c80, nrow = vy1 - vy0;
             const int rpi = (int)(64.0f / (float)ncol);                  // floor(64 / ncol), ncol in 1..64 (exact: IEEE divide)
-            int lr = (int)((float)lane / (float)ncol);
-            if (lr * ncol > lane) --lr; else if ((lr + 1) * ncol <= lane) ++lr;
+            // lane / ncol by a wave-uniform reciprocal: magic = ceil(2^16 / ncol) is exact for lane < 64, ncol <= 64
+            const int magic = (int)ceilf(65536.0f / (float)ncol);        // == ceil(65536 / ncol) for ncol <= 64 (checked exhaustively)
+            const int lr = (int)(((u32)lane * (u32)magic) >> 16);
             const int lc = lane - lr * ncol;
             const bool lact = lr < rpi;
             const int tx8 = (c80 + lc) << 3;
             // survivor flags live in a sparse layout: pixel k of the lane's 8 at bit 4k+3 (that is where two v_perm drop
-            // the sign bits; popcount and ctz do not care about the spacing, and ascending bits are ascending x)
-            u32 colmask = 0;
-#pragma unroll
-            for (int bb = 0; bb < 8; ++bb)
-                colmask |= (tx8 + bb >= cx0 && tx8 + bb < cx1 && lact) ? 8u << (4 * bb) : 0u;   // idle lanes: empty mask
+            // the sign bits; popcount and ctz do not care about the spacing, and ascending bits are ascending x).
+            // colmask = the lane's pixels inside [cx0, cx1): nibbles [lo, hi) of 0x88888888 (empty for idle lanes)
+            const int lo = min(max(cx0 - tx8, 0), 8), hi = lact ? min(max(cx1 - tx8, 0), 8) : 0;
+            const u32 below_hi = hi >= 8 ? 0xFFFFFFFFu : (1u << (4 * hi)) - 1u;
+            const u32 below_lo = lo >= 8 ? 0xFFFFFFFFu : (1u << (4 * lo)) - 1u;
+            const u32 colmask = 0x88888888u & below_hi & ~below_lo;
             for (int pass = 0; pass < 2; ++pass) {
                 const int t = pass == 0 ? g.iniTh : g.minTh;
                 if (pass == 1 && g.minTh >= g.iniTh) break;               // a higher retry threshold cannot add corners
