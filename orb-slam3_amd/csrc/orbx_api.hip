@@ -440,20 +440,19 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
             hipMalloc((void**)&o->dN, sizeof(int) * B) != hipSuccess || hipMalloc((void**)&o->dMono, sizeof(int) * B) != hipSuccess ||
             hipMalloc((void**)&o->dLap, sizeof(int) * 2 * B) != hipSuccess || hipMalloc((void**)&o->dErr, sizeof(int)) != hipSuccess ||
             hipMalloc((void**)&o->dPattern, 1024) != hipSuccess || hipMalloc((void**)&o->dOdW, sizeof(u32) * OD_WTAB) != hipSuccess || hipMalloc((void**)&o->dOvf, 2 * sizeof(u32)) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
-        {   // IC_Angle weights for v_dot4: entry [al][|v|][j] packs, for the 4 bytes of patch dword j of a row at distance |v| from
-            // the centre, (u + 16) where the pixel lies inside the disc (|u| <= umax[|v|]) and 0 elsewhere; u = 4j + b - 15 - al,
-            // al = (cx - 15) & 3 = where the patch starts inside its first aligned dword.  Row 16 is all zero (rows past the patch).
+        {   // IC_Angle weights for v_dot4: entry [|v|][j] packs, for the 4 bytes of dword j of a 32-byte patch row (it starts at
+            // cx-15) at distance |v| from the centre, (u + 16) where the pixel lies inside the disc (|u| <= umax[|v|]) and 0
+            // elsewhere; u = 4j + b - 15.  Row 16 is all zero (lanes past the 31st row).
             std::vector<u32> wt(OD_WTAB, 0u);
-            for (int al = 0; al < 4; ++al)
-                for (int va = 0; va < 16; ++va)
-                    for (int j = 0; j < 9; ++j) {
-                        u32 wv = 0;
-                        for (int b = 0; b < 4; ++b) {
-                            const int u = 4 * j + b - 15 - al;
-                            if (std::abs(u) <= o->umax.v[va]) wv |= (u32)(u + 16) << (8 * b);
-                        }
-                        wt[(al * 17 + va) * 9 + j] = wv;
+            for (int va = 0; va < 16; ++va)
+                for (int j = 0; j < 8; ++j) {
+                    u32 wv = 0;
+                    for (int b = 0; b < 4; ++b) {
+                        const int u = 4 * j + b - 15;
+                        if (std::abs(u) <= o->umax.v[va]) wv |= (u32)(u + 16) << (8 * b);
                     }
+                    wt[va * 8 + j] = wv;
+                }
             if (hipMemcpy(o->dOdW, wt.data(), sizeof(u32) * OD_WTAB, hipMemcpyHostToDevice) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMemcpy failed"); break; }
         }
         if (hipMemcpy(o->dPattern, kPattern, 1024, hipMemcpyHostToDevice) != hipSuccess || hipMemset(o->dErr, 0, sizeof(int)) != hipSuccess || hipMemset(o->dOvf, 0, 2 * sizeof(u32)) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMemcpy failed"); break; }

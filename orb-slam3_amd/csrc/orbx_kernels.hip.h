@@ -1387,15 +1387,16 @@ __global__ __launch_bounds__(256) void k_orient_desc(Geom g, const u8* const* l0
 // k_orient_desc2: FOUR keypoints per wavefront (16 lanes each) -- same arithmetic as k_orient_desc, a quarter of
 // the waves and 4x the bytes in flight per wave (the first version was pure memory latency: 3 dependent trips
 // per keypoint at 642 VALU instructions each).
-//  * IC_Angle: the 31 patch rows are fetched as 9 aligned dwords per row (279 dword loads per keypoint, 4.4 per
-//    lane) and weighted per byte; moments are wave-reduced once per keypoint.
+//  * IC_Angle: the 31 patch rows are fetched as 8 dwords per row starting exactly at cx-15 (unaligned global loads: 248
+//    dword loads per keypoint, 4 per lane) and reduced with v_dot4 against per-row byte weights held in LDS; moments
+//    are wave-reduced once per keypoint.
 //  * fastAtan2 / sin / cos run ONCE per wave for 4 different angles (lane group = keypoint).
 //  * rBRIEF: lane s of a group evaluates pairs {16q + s}; one __ballot per q yields, for all 4 keypoints at once,
 //    descriptor bytes 2q and 2q+1 already in LSB-first bit order (bit s of the group's 16-bit field).
 //    The 512 pattern points sit in LDS as floats (staged once per workgroup).
 // ------------------------------------------------------------------------------------------------
 #define OD_PPITCH 40
-#define OD_WTAB (4 * 17 * 9)                               // IC_Angle weight table: [alignment][|v| (16 = zero row)][dword]
+#define OD_WTAB (17 * 8)                                   // IC_Angle weight table: [|v| (16 = zero row)][dword of the 32-byte patch row]
 #define OD_PATCH (37 * OD_PPITCH)
 __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
                                                       const u8* blr, const KpWork* __restrict__ work,
@@ -1420,16 +1421,14 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
     const int p = base + sub;
     const bool valid = p < n;
     const KpWork w = work[(size_t)frame * g.kpCap + (valid ? p : base)];
-    // ---- orientation: all 64 lanes work on one keypoint's 31 x 9 dwords at a time; the 4 x 5 loads of the whole
+    // ---- orientation: all 64 lanes work on one keypoint's 31 x 8 dwords at a time; the 4 x 4 loads of the whole
     // wave are issued before any arithmetic (one memory round trip instead of four)
     int m10s[4] = {0, 0, 0, 0}, m01s[4] = {0, 0, 0, 0};
-    u32 dq[4][5], bq[4][6];
-    int cxs[4], xals[4];
+    u32 dq[4][4], bq[4][6];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        cxs[k] = 0; xals[k] = 0;
 #pragma unroll
-        for (int it = 0; it < 5; ++it) dq[k][it] = 0;
+        for (int it = 0; it < 4; ++it) dq[k][it] = 0;
 #pragma unroll
         for (int it = 0; it < 6; ++it) bq[k][it] = 0;
         if (base + k < n) {                                     // wave-uniform
@@ -1438,14 +1437,12 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
             const int cy = __builtin_amdgcn_readlane((int)w.y, 16 * k);
             int sp;
             const u8* im = level_ptr(g, l0, l0pitch, pyr, frame, level, &sp);
-            const int xal = (cx - 15) & ~3;
-            cxs[k] = cx; xals[k] = xal;
+            // 31 rows x 8 dwords starting exactly at cx-15 (global loads take any byte alignment): 248 dwords = 4 per lane
 #pragma unroll
-            for (int it = 0; it < 5; ++it) {
+            for (int it = 0; it < 4; ++it) {
                 const int idx = it * 64 + lane;
-                const int r = (idx * 57) >> 9;                  // idx / 9 for idx < 320
-                const int j = idx - r * 9;
-                if (r < 31) dq[k][it] = gload32u(im, (u32)(__mul24(cy + r - 15, sp) + xal + 4 * j));
+                const int r = idx >> 3, j = idx & 7;
+                if (r < 31) dq[k][it] = gload32u(im, (u32)(__mul24(cy + r - 15, sp) + cx - 15 + 4 * j));
             }
             // blurred patch: rows cy-18..cy+18, 10 aligned dwords from (cx-18)&~3
             const LevelDesc& Lk = g.lv[level];
@@ -1476,24 +1473,22 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
     // IC_Angle moments with v_dot4: per patch dword  S1 = sum (u+16)*I over the disc, S2 = sum I over the disc;
     // m10 = S1 - 16*S2, m01 = sum over rows of v*S2.  The weights come from LDS ([alignment][|v|][dword]); the in-disc
     // 0/1 bytes are the non-zero bytes of the weight word (u + 16 >= 1 inside the disc).
-    int tbl[5], vrow[5];
+    int tbl[4], vrow[4];
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {
+    for (int it = 0; it < 4; ++it) {
         const int idx = it * 64 + lane;
-        const int r = (idx * 57) >> 9;
-        const int v = r - 15;
+        const int v = (idx >> 3) - 15;
         vrow[it] = v;
-        tbl[it] = min(v < 0 ? -v : v, 16) * 9 + (idx - r * 9);
+        tbl[it] = min(v < 0 ? -v : v, 16) * 8 + (idx & 7);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (base + k < n) {
-            const u32* wk = sW + ((cxs[k] - 15) & 3) * (17 * 9);
             u32 a1 = 0, a2 = 0;
             int m01 = 0;
 #pragma unroll
-            for (int it = 0; it < 5; ++it) {
-                const u32 w1 = wk[tbl[it]];
+            for (int it = 0; it < 4; ++it) {
+                const u32 w1 = sW[tbl[it]];
                 const u32 w2 = ((w1 + 0x7F7F7F7Fu) & 0x80808080u) >> 7;
                 a1 = __builtin_amdgcn_udot4(dq[k][it], w1, a1, false);
                 const u32 s2 = __builtin_amdgcn_udot4(dq[k][it], w2, 0u, false);
