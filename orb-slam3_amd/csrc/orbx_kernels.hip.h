@@ -1250,12 +1250,10 @@ __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int 
     auto fetch = [&](int r0) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
-            const int r = r0 + k;
-            Bn[k] = 0;
-            if (r < nrows) {
-                const int ys = reflect101(t.y0 - 3 + r, h);
-                Bn[k] = gload32u(im + (size_t)ys * sp, (u32)gcl * 4u);       // uniform row base + per-lane byte offset
-            }
+            // rows past the block are clamped, not skipped: no zero-initialised destination, no branch (their sums are never used)
+            const int r = min(r0 + k, nrows - 1);
+            const int ys = reflect101(t.y0 - 3 + r, h);
+            Bn[k] = gload32u(im + (size_t)ys * sp, (u32)gcl * 4u);           // uniform row base + per-lane byte offset
         }
     };
     fetch(0);
@@ -1270,9 +1268,9 @@ __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int 
             const int r = r0 + k;
             if (r < nrows) {
                 const u32 B = Bq[k];
-                u32 A = (u32)__builtin_amdgcn_update_dpp(0, (int)B, 0x138, 0xf, 0xf, false);       // wave_shr:1 = left neighbour's dword
+                u32 A = (u32)__builtin_amdgcn_mov_dpp((int)B, 0x138, 0xf, 0xf, true);             // wave_shr:1 = left neighbour's dword (no `old` operand to materialise)
                 const u32 Bf = isGl ? __builtin_amdgcn_perm(A, B, selB) : B;                     // reflect the bytes beyond the last pixel
-                u32 C = (u32)__builtin_amdgcn_update_dpp(0, (int)Bf, 0x130, 0xf, 0xf, false);      // wave_shl:1 = right neighbour's dword
+                u32 C = (u32)__builtin_amdgcn_mov_dpp((int)Bf, 0x130, 0xf, 0xf, true);            // wave_shl:1 = right neighbour's dword
                 C = isGl ? __builtin_amdgcn_perm(A, B, selC) : C;                                 // the dword beyond the image
                 A = isG0 ? __builtin_amdgcn_perm(C, Bf, 0x01020304u) : A;                         // pixels -4..-1 <- 4,3,2,1
                 const u32 w1[4] = {__builtin_amdgcn_alignbyte(Bf, A, 1), __builtin_amdgcn_alignbyte(Bf, A, 2),
