@@ -55,3 +55,43 @@ def test_gpu_reproduces_golden_knn2(pkg):
     g = _load("knn2_120x150.npz")
     idx, dist = pkg.ORBmatcher(0.7).knn2(g["q"], g["t"])
     assert np.array_equal(idx, g["idx"]) and np.array_equal(dist, g["dist"])
+
+
+def _geometry_outputs(M, gray, g):
+    und = M.UndistortKeyPoints(g["kps"], g["K"], g["D"])
+    bounds = M.ComputeImageBounds(752, 480, g["K"], g["D"])
+    cnt, fr = M.isInFrustum(g["Pw"], g["normal"], g["min_dist"], g["max_dist"], g["R"], g["t"], g["Ow"], g["K"], g["bounds"],
+                            47.90639, 0.5, float(g["lsf"]), 8)
+    return und, bounds, cnt, fr
+
+
+def _check_geometry(und, bounds, cnt, fr, g):
+    assert und.tobytes() == g["und"].tobytes() and bounds.tobytes() == g["bounds"].tobytes() and cnt == int(g["cnt"])
+    v = g["fr_in_view"].astype(bool)
+    for k in ("in_view", "proj_x", "proj_y"):
+        assert fr[k].tobytes() == g["fr_" + k].tobytes(), k
+    for k in ("proj_xr", "depth", "level", "view_cos"):
+        assert fr[k][v].tobytes() == g["fr_" + k][v].tobytes(), k
+
+
+def test_oracle_reproduces_golden_geometry(oracle):
+    """tools/gen_golden_geometry.py: undistort / image bounds / frustum / cvtColor vectors (oracle-generated, parity unpinned)."""
+    g = _load("geometry.npz")
+    M = oracle._oracle_matcher_class()()
+    _check_geometry(*_geometry_outputs(M, None, g), g)
+    assert np.array_equal(oracle.gray_from_color(g["rgb"], False, 14), g["gray14_rgb"])
+    assert np.array_equal(oracle.gray_from_color(g["rgb"], True, 15), g["gray15_bgr"])
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_geometry(pkg):
+    g = _load("geometry.npz")
+    _check_geometry(*_geometry_outputs(pkg.ORBmatcher(), None, g), g)
+    ex = pkg.ORBextractor(300, max_size=(320, 240))
+    try:
+        for blue_first, bits, key in ((False, 14, "gray14_rgb"), (True, 15, "gray15_bgr")):
+            buf, stride = ex.gray_from_color([g["rgb"]], blue_first, bits)
+            h, w = g["rgb"].shape[:2]
+            assert np.array_equal(buf.download(np.uint8, stride * h).reshape(h, stride)[:, :w], g[key])
+    finally:
+        ex.close()
