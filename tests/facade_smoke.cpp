@@ -3,6 +3,7 @@
 #include <vector>
 #include "../orb-slam3_amd/facade/ORBextractor.h"
 #include "../orb-slam3_amd/facade/ORBmatcher.h"
+#include "../orb-slam3_amd/facade/FrameGeometry.h"
 
 int main(int argc, char** argv) {
     const int w = 752, h = 480;
@@ -22,5 +23,18 @@ int main(int argc, char** argv) {
     if (ex.mvImagePyramid[1].cols != 627) return 3;
     ORB_SLAM3::ORBmatcher m(0.7f);
     if (ORB_SLAM3::ORBmatcher::DescriptorDistance(desc.row(0), desc.row(0)) != 0) return 4;
+    {   // Frame-level helpers: undistorted keypoints stay put at the principal point, bounds grow for k1 < 0
+        const float K[4] = {458.654f, 457.296f, 367.215f, 248.375f};
+        const std::vector<float> D = {-0.28340811f, 0.07395907f, 0.00019359f, 1.76187114e-05f};
+        std::vector<cv::KeyPoint> un;
+        ORB_SLAM3::UndistortKeyPoints(m.handle(), kps, K, D, K, un);
+        float x0, x1, y0, y1;
+        ORB_SLAM3::ComputeImageBounds(m.handle(), w, h, K, D, K, x0, x1, y0, y1);
+        if (un.size() != kps.size() || !(x0 < 0.f && x1 > (float)w && y0 < 0.f && y1 > (float)h)) return 5;
+        ORB_SLAM3::FrustumOut fo;
+        const float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0}, O[3] = {0, 0, 0}, b[4] = {x0, x1, y0, y1};
+        const int nin = ORB_SLAM3::IsInFrustumBatch(m.handle(), {0.f, 0.f, 4.f}, {0.f, 0.f, 1.f}, {0.5f}, {6.f}, R, t, O, K, b, 47.9f, 0.5f, 0.18232156f, 8, fo);
+        if (nin != 1 || fo.level[0] < 0) return 6;
+    }
     return 0;
 }
