@@ -13,5 +13,5 @@ for r in csv.DictReader(open(f)):
     k = r['Kernel_Name'].split('(')[0]
     acc[k][r['Counter_Name']] += float(r['Counter_Value']); n[k][r['Counter_Name']] += 1
 for k, v in acc.items():
-    if 'k_fast3' in k: print('$lib', {c: round(x / n[k][c] * 2) for c, x in v.items()})   # x2: two launches per step
+    if 'k_fast3' in k: print('$lib', {c: round(x / n[k][c]) for c, x in v.items()}, '(average per launch; three k_fast3 launches per step)')
 PY
