@@ -61,6 +61,8 @@ struct orbx {
     size_t qtLds = 0, qt2Lds = 0;
     int qt2Cap = 0, qt2Sort = 0;
     bool qtV1 = false, odV1 = false, serial = false;
+    bool qtWide = false;                                       // 1024-thread quadtree workgroups (large frames / feature counts)
+    int qtWideForce = -1;                                      // ORBX_QT_WIDE=0/1: A/B switch
     // device
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;
@@ -298,6 +300,7 @@ static int build_geometry(orbx* o, int w, int h) {
         o->qt2Sort = sc2;
         o->maxCells = 0;
         for (int l = 0; l < L; ++l) o->maxCells = std::max(o->maxCells, g.lv[l].nCells);
+        o->qtWide = o->qtWideForce >= 0 ? o->qtWideForce != 0 : maxN >= 512;   // many features per level: 1024-thread workgroups
         o->qt2Lds = (size_t)sc2 * 8 + (size_t)o->qt2Cap * (16 * 2 + 16 + 4 + 4 + 8 + 2 + 1 + 1) + (size_t)(o->maxCells + 1) * 4 + 64;
         if (o->qt2Lds > 160 * 1024 - 512) { set_err("quadtree for %d features/level needs %zu B of LDS (> 160 KiB)", maxN, o->qt2Lds); return ORBX_E_UNSUPPORTED; }
     }
@@ -376,7 +379,8 @@ static int build_geometry(orbx* o, int w, int h) {
     }
     if (ensure(&o->dOvfList, &o->capOvfList, (size_t)g.totalCells * B)) return ORBX_E_HIP;
     HIPCHK(hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->qtLds));
-    HIPCHK(hipFuncSetAttribute((const void*)k_quadtree2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->qt2Lds));
+    HIPCHK(hipFuncSetAttribute((const void*)k_quadtree2<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->qt2Lds));
+    HIPCHK(hipFuncSetAttribute((const void*)k_quadtree2<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->qt2Lds));
     o->curW = w; o->curH = h;
     return 0;
 }
@@ -410,6 +414,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     o->qtV1 = getenv("ORBX_QT_V1") != nullptr;
     o->odV1 = getenv("ORBX_OD_V1") != nullptr;
     if (const char* e = getenv("ORBX_FAST_QCAP")) o->f3QcapForce = atoi(e);
+    if (const char* e = getenv("ORBX_QT_WIDE")) o->qtWideForce = atoi(e) != 0 ? 1 : 0;
     o->serial = getenv("ORBX_SERIAL") != nullptr;            // A/B switch: simple per-cell reference kernel
     o->scaleFactor = scale_factor;                              // double member initialised from float (ORBextractor.h:96)
     const int L = nlevels;
@@ -592,8 +597,12 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
                            o->dKpNode, o->dSel, o->dSelCnt, o->dErr);
     else {
         Geom g2 = g; g2.nodeCap = o->qt2Cap; g2.sortCap = o->qt2Sort;
-        hipLaunchKernelGGL(k_quadtree2, dim3(nimg, g.nlevels), dim3(256), o->qt2Lds, st, g2, o->dCandCnt, o->dCandEnt,
-                           o->dDense, o->dKpNode, o->dSel, o->dSelCnt, o->dErr, o->maxCells);
+        if (o->qtWide)
+            hipLaunchKernelGGL(k_quadtree2<1024>, dim3(nimg, g.nlevels), dim3(1024), o->qt2Lds, st, g2, o->dCandCnt, o->dCandEnt,
+                               o->dDense, o->dKpNode, o->dSel, o->dSelCnt, o->dErr, o->maxCells);
+        else
+            hipLaunchKernelGGL(k_quadtree2<256>, dim3(nimg, g.nlevels), dim3(256), o->qt2Lds, st, g2, o->dCandCnt, o->dCandEnt,
+                               o->dDense, o->dKpNode, o->dSel, o->dSelCnt, o->dErr, o->maxCells);
     }
     HIPCHK(hipEventRecord(o->ev[3], st));
     hipLaunchKernelGGL(k_slots, dim3(nimg), dim3(256), 0, st, g, o->dSel, o->dSelCnt, o->dLap, o->dKps, o->dWork, o->dN, o->dMono);

@@ -889,9 +889,10 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const CellInfo* __rest
 // ------------------------------------------------------------------------------------------------
 struct QNode { short4 r; u32 cnt; u32 seq; };
 
+template <int NT>
 __device__ __forceinline__ u32 block_scan_excl(u32* a, int n, u32* wsum, int tid) {
     const int lane = tid & 63, wv = tid >> 6;
-    const int per = (n + 255) >> 8;
+    const int per = (n + NT - 1) / NT;
     const int b = min(tid * per, n), e = min(b + per, n);
     u32 s = 0;
     for (int i = b; i < e; ++i) s += a[i];
@@ -903,7 +904,9 @@ __device__ __forceinline__ u32 block_scan_excl(u32* a, int n, u32* wsum, int tid
     __syncthreads();
     u32 base = 0;
     for (int k = 0; k < wv; ++k) base += wsum[k];
-    const u32 total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    u32 total = 0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) total += wsum[k];
     u32 run = base + inc - s;
     for (int i = b; i < e; ++i) { const u32 v = a[i]; a[i] = run; run += v; }
     __syncthreads();
@@ -917,7 +920,10 @@ __device__ __forceinline__ short4 qt_child_rect(short4 r, int q) {
                        (short)((q & 1) ? r.z : mx), (short)((q & 2) ? r.w : my));
 }
 
-__global__ __launch_bounds__(256) void k_quadtree2(Geom g, const u32* __restrict__ candCnt, const u32* __restrict__ candEnt,
+// NT = workgroup size: NT for the usual few thousand candidates per level, 1024 when a level has tens of thousands (1080p
+// with 4000 features: the single workgroup per (frame, level) is the whole parallelism of this latency-bound kernel).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict__ candCnt, const u32* __restrict__ candEnt,
                                                    u32* dense, u16* kpNode, u32* selOut, u32* selCnt, int* err, int maxCells) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // grid = (frames, levels): consecutive workgroup ids go round-robin over the 8 XCDs, so the fastest-varying index must
@@ -937,7 +943,7 @@ __global__ __launch_bounds__(256) void k_quadtree2(Geom g, const u32* __restrict
     u16* newPos = childPos + cap * 4;
     u8* nch = (u8*)(newPos + cap);
     u8* proc = nch + cap;
-    __shared__ u32 wsum[4];
+    __shared__ u32 wsum[NT / 64];
     __shared__ int s_size, s_state, s_seqBase, s_cnt, s_ncand;
     const u32* cnts = candCnt + (size_t)frame * g.totalCells + L.cellBase;
     const u32* ents = candEnt + (size_t)frame * g.totalSlots + L.slotBase;
@@ -947,13 +953,13 @@ __global__ __launch_bounds__(256) void k_quadtree2(Geom g, const u32* __restrict
 
     // ---- gather the per-cell slot arrays into one dense list (cells are stored in reference order)
     const int nCells = L.nCells;
-    for (int c = tid; c < nCells; c += 256) cellOff[c] = cnts[c];
-    for (int i = tid; i < cap; i += 256) s1[i] = 0;
+    for (int c = tid; c < nCells; c += NT) cellOff[c] = cnts[c];
+    for (int i = tid; i < cap; i += NT) s1[i] = 0;
     __syncthreads();
-    const int nk = (int)block_scan_excl(cellOff, nCells, wsum, tid);
+    const int nk = (int)block_scan_excl<NT>(cellOff, nCells, wsum, tid);
     if (tid == 0) cellOff[nCells] = (u32)nk;
     __syncthreads();
-    for (int i = tid; i < nk; i += 256) {
+    for (int i = tid; i < nk; i += NT) {
         int lo = 0, hi = nCells;                             // last cell with cellOff <= i
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)cellOff[mid] <= i) lo = mid; else hi = mid; }
         const u32 e = ents[lo * L.slotCap + (i - (int)cellOff[lo])];
@@ -964,7 +970,7 @@ __global__ __launch_bounds__(256) void k_quadtree2(Geom g, const u32* __restrict
     }
     __syncthreads();
 
-#define QT_FOR_KP(BODY) for (int ki = tid; ki < nk; ki += 256) { const u32 e = de[ki]; BODY }
+#define QT_FOR_KP(BODY) for (int ki = tid; ki < nk; ki += NT) { const u32 e = de[ki]; BODY }
 
     // ---- roots (ORBextractor.cc:695-763)
     if (tid == 0) {
@@ -988,24 +994,24 @@ __global__ __launch_bounds__(256) void k_quadtree2(Geom g, const u32* __restrict
         if (state == 2) break;
         if (iter > 4096) { if (tid == 0) atomicExch(err, 4); break; }
         // (1) quadrant histograms of every splittable node
-        for (int i = tid; i < size * 4; i += 256) qc[i] = 0;
+        for (int i = tid; i < size * 4; i += NT) qc[i] = 0;
         if (tid == 0) { s_cnt = 0; s_ncand = 0; }
         __syncthreads();
         QT_FOR_KP({ const int nd = kn[ki]; if (A[nd].cnt > 1) atomicAdd(&qc[nd * 4 + qt_quadrant(A[nd].r, e & 0xFFF, (e >> 12) & 0xFFF)], 1u); })
         __syncthreads();
         int totalCh = 0, newSize = 0;
         if (state == 0) {                                                    // ORBextractor.cc:779-895
-            for (int i = tid; i < size; i += 256) {
+            for (int i = tid; i < size; i += NT) {
                 int c = 0;
                 if (A[i].cnt > 1) c = (qc[i * 4] > 0) + (qc[i * 4 + 1] > 0) + (qc[i * 4 + 2] > 0) + (qc[i * 4 + 3] > 0);
                 nch[i] = (u8)c; proc[i] = c > 0;
                 s1[i] = c; s2[i] = c > 0 ? 0 : 1;
             }
             __syncthreads();
-            totalCh = (int)block_scan_excl(s1, size, wsum, tid);
-            const int totalKeep = (int)block_scan_excl(s2, size, wsum, tid);
+            totalCh = (int)block_scan_excl<NT>(s1, size, wsum, tid);
+            const int totalKeep = (int)block_scan_excl<NT>(s2, size, wsum, tid);
             newSize = totalCh + totalKeep;
-            for (int i = tid; i < size; i += 256) {
+            for (int i = tid; i < size; i += NT) {
                 const int c = nch[i];
                 if (c > 0) {
                     const int blockStart = totalCh - (int)s1[i] - c;
@@ -1029,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_quadtree2(Geom g, const u32* __restrict
         } else {                                                             // ORBextractor.cc:912-992
             int n2 = 1;
             while (n2 < size) n2 <<= 1;
-            for (int i = tid; i < n2; i += 256) {
+            for (int i = tid; i < n2; i += NT) {
                 unsigned long long key = 0;
                 if (i < size && A[i].cnt > 1) {
                     key = ((unsigned long long)A[i].cnt << 40) | ((unsigned long long)A[i].seq << 16) | (unsigned)i;
@@ -1045,7 +1051,7 @@ __global__ __launch_bounds__(256) void k_quadtree2(Geom g, const u32* __restrict
             __syncthreads();
             for (int k = 2; k <= n2; k <<= 1)
                 for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int i = tid; i < n2; i += 256) {
+                    for (int i = tid; i < n2; i += NT) {
                         const int ixj = i ^ j;
                         if (ixj > i) {
                             const unsigned long long a = sortKey[i], b = sortKey[ixj];
@@ -1057,11 +1063,11 @@ __global__ __launch_bounds__(256) void k_quadtree2(Geom g, const u32* __restrict
                 }
             const int ncand = s_ncand;
             // processing order k = 0.. : largest (count, seq) first = sortKey[n2-1-k]
-            for (int k = tid; k < ncand; k += 256) s1[k] = (u32)nch[(int)(sortKey[n2 - 1 - k] & 0xFFFF)] - 1u;
+            for (int k = tid; k < ncand; k += NT) s1[k] = (u32)nch[(int)(sortKey[n2 - 1 - k] & 0xFFFF)] - 1u;
             __syncthreads();
-            block_scan_excl(s1, ncand, wsum, tid);
+            block_scan_excl<NT>(s1, ncand, wsum, tid);
             // the reference stops right after the split that makes size >= N: count the splits that leave size < N
-            for (int k = tid; k < ncand; k += 256) {
+            for (int k = tid; k < ncand; k += NT) {
                 const int gain = (int)nch[(int)(sortKey[n2 - 1 - k] & 0xFFFF)] - 1;
                 if (size + (int)s1[k] + gain < N) atomicAdd(&s_cnt, 1);
             }
@@ -1069,18 +1075,18 @@ __global__ __launch_bounds__(256) void k_quadtree2(Geom g, const u32* __restrict
             const int P = min(ncand, s_cnt + 1);
             __syncthreads();
             if (tid == 0) s_cnt = 0;
-            for (int k = tid; k < ncand; k += 256) {
+            for (int k = tid; k < ncand; k += NT) {
                 const int id = (int)(sortKey[n2 - 1 - k] & 0xFFFF);
                 s1[k] = k < P ? (u32)nch[id] : 0u;
                 if (k < P) proc[id] = 1;
             }
             __syncthreads();
-            for (int i = tid; i < size; i += 256) s2[i] = proc[i] ? 0 : 1;
+            for (int i = tid; i < size; i += NT) s2[i] = proc[i] ? 0 : 1;
             __syncthreads();
-            totalCh = (int)block_scan_excl(s1, ncand, wsum, tid);
-            const int totalKeep = (int)block_scan_excl(s2, size, wsum, tid);
+            totalCh = (int)block_scan_excl<NT>(s1, ncand, wsum, tid);
+            const int totalKeep = (int)block_scan_excl<NT>(s2, size, wsum, tid);
             newSize = totalCh + totalKeep;
-            for (int k = tid; k < P; k += 256) {
+            for (int k = tid; k < P; k += NT) {
                 const int i = (int)(sortKey[n2 - 1 - k] & 0xFFFF);
                 const int c = nch[i];
                 const int blockStart = totalCh - (int)s1[k] - c;
@@ -1096,7 +1102,7 @@ __global__ __launch_bounds__(256) void k_quadtree2(Geom g, const u32* __restrict
                     }
                 }
             }
-            for (int i = tid; i < size; i += 256)
+            for (int i = tid; i < size; i += NT)
                 if (!proc[i]) { const int pos = totalCh + (int)s2[i]; B[pos] = A[i]; newPos[i] = (u16)pos; }
         }
         __syncthreads();
@@ -1118,12 +1124,12 @@ __global__ __launch_bounds__(256) void k_quadtree2(Geom g, const u32* __restrict
     // ---- one keypoint per node: first maximum of `response` in candidate order (ORBextractor.cc:1005-1030)
     const int nsel = s_size;
     u32* best = qc;
-    for (int i = tid; i < nsel; i += 256) best[i] = 0;
+    for (int i = tid; i < nsel; i += NT) best[i] = 0;
     __syncthreads();
     QT_FOR_KP({ atomicMax(&best[kn[ki]], ((e >> 24) << 24) | (0xFFFFFFu - (u32)ki)); })
     __syncthreads();
     u32* so = selOut + (size_t)frame * g.totalSel + L.selBase;
-    for (int i = tid; i < nsel; i += 256) {
+    for (int i = tid; i < nsel; i += NT) {
         if (i < L.selCap) so[i] = de[0xFFFFFFu - (best[i] & 0xFFFFFFu)];
         else atomicExch(err, 3);
     }

@@ -137,7 +137,8 @@ def test_ab_reference_kernels_stay_bit_exact(pkg, oracle, synth, monkeypatch):
     stream) are kept as A/B references behind environment switches read at orbx_create: they must give the same bits."""
     img = synth.gen_image(752, 480, 21)
     n_ref, kps_ref, desc_ref, mono_ref = oracle.Extractor(1000)(img, (0, 1000))
-    for env in (["ORBX_FAST_V1"], ["ORBX_QT_V1"], ["ORBX_OD_V1"], ["ORBX_SERIAL"], ["ORBX_FAST_V1", "ORBX_QT_V1", "ORBX_OD_V1", "ORBX_SERIAL"]):
+    for env in (["ORBX_FAST_V1"], ["ORBX_QT_V1"], ["ORBX_OD_V1"], ["ORBX_SERIAL"], ["ORBX_QT_WIDE"],
+                ["ORBX_FAST_V1", "ORBX_QT_V1", "ORBX_OD_V1", "ORBX_SERIAL"]):
         for e in env:
             monkeypatch.setenv(e, "1")
         ex = pkg.ORBextractor(1000, max_size=(752, 480))
