@@ -104,6 +104,12 @@ int orbx_stream_wait_other(orbx_t*, void* other_stream);
  * orbx_extract_batch_async). */
 int orbx_gray_from_color(orbx_t*, const uint8_t* const* src, int src_space, int nimg, int w, int h, int src_stride,
                          int channels, int blue_first, int coef_bits, uint8_t* const* dst, int dst_stride);
+/* SURVEY 8(f).4 stereo rectification -- replaces cv::remap(im, imRect, M1, M2, cv::INTER_LINEAR) of the stereo examples
+ * (Examples/Stereo/stereo_euroc.cc:168-169) for 8-bit single-channel images with CV_32F maps, BORDER_CONSTANT 0.
+ * src[i] / dst[i] / mapx / mapy are DEVICE pointers (the maps are uploaded once, e.g. with orbx_dev_alloc + orbx_memcpy_h2d);
+ * maps and destination are dw x dh.  Enqueued on the extractor's stream. */
+int orbx_remap_linear(orbx_t*, const uint8_t* const* src, int nimg, int sw, int sh, int src_stride, const float* mapx, const float* mapy,
+                      int dw, int dh, uint8_t* const* dst, int dst_stride);
 /* algorithmic bytes of the pyramid+FAST pass for one frame of the current geometry */
 int64_t orbx_algorithmic_bytes(const orbx_t*, int64_t* fused_lower_bound);
 void* orbx_stream(const orbx_t*);     /* hipStream_t the kernels are launched on */

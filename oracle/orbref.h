@@ -228,6 +228,14 @@ int orbref_is_in_frustum(int n, const float* pw, const float* normal, const floa
 int orbref_gray_from_color(const uint8_t* src, int w, int h, int src_stride, int channels, int blue_first, int coef_bits,
                            uint8_t* dst, int dst_stride);
 
+/* SURVEY 8(f).4 stereo rectification: cv::remap(src, dst, map1, map2, INTER_LINEAR) for CV_8UC1 with CV_32FC1 maps
+ * (Examples/Stereo/stereo_euroc.cc:168-169), default BORDER_CONSTANT 0.  OpenCV's fixed-point path restated: coordinates
+ * cvRound(map * 32) -> integer part >> 5, 5-bit fractions (INTER_BITS); weights (32-fx)(32-fy)*32 ... fx*fy*32 (they sum to
+ * 1 << 15 exactly, so the table's sum correction never triggers for INTER_LINEAR); dst = (sum + (1 << 14)) >> 15; taps
+ * outside the source read 0.  OpenCV version unpinned -> parity unpinned. */
+int orbref_remap_linear(const uint8_t* src, int sw, int sh, int src_stride, const float* mapx, const float* mapy,
+                        int dw, int dh, uint8_t* dst, int dst_stride);
+
 #ifdef __cplusplus
 }
 #endif

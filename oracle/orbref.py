@@ -236,6 +236,19 @@ def gray_from_color(img, blue_first=False, coef_bits=15):
     return out
 
 
+def remap_linear(img, mapx, mapy):
+    """cv::remap(img, mapx, mapy, INTER_LINEAR), BORDER_CONSTANT 0, restated (orbref_remap_linear)."""
+    L = lib()
+    L.orbref_remap_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    img = np.ascontiguousarray(img, np.uint8); mx = np.ascontiguousarray(mapx, np.float32); my = np.ascontiguousarray(mapy, np.float32)
+    sh, sw = img.shape; dh, dw = mx.shape
+    out = np.zeros((dh, dw), np.uint8)
+    rc = L.orbref_remap_linear(_p(img), sw, sh, sw, _p(mx), _p(my), dw, dh, _p(out), dw)
+    if rc:
+        raise RuntimeError("orbref_remap_linear failed with code %d" % rc)
+    return out
+
+
 # ---- DBoW2 vocabulary transform (oracle side) ----
 class Vocabulary:
     def __init__(self, path):

@@ -983,4 +983,19 @@ int orbref_gray_from_color(const uint8_t* src, int w, int h, int src_stride, int
     return 0;
 }
 
+int orbref_remap_linear(const uint8_t* src, int sw, int sh, int src_stride, const float* mapx, const float* mapy,
+                        int dw, int dh, uint8_t* dst, int dst_stride) {
+    if (!src || !mapx || !mapy || !dst || sw < 1 || sh < 1 || dw < 1 || dh < 1) return -2;
+    auto at = [&](int x, int y) -> int { return (x >= 0 && x < sw && y >= 0 && y < sh) ? src[(size_t)y * src_stride + x] : 0; };
+    for (int y = 0; y < dh; ++y)
+        for (int x = 0; x < dw; ++x) {
+            const int sx = (int)lrintf(mapx[(size_t)y * dw + x] * 32.f), sy = (int)lrintf(mapy[(size_t)y * dw + x] * 32.f);   // cvRound(map * INTER_TAB_SIZE)
+            const int ix = sx >> 5, iy = sy >> 5, fx = sx & 31, fy = sy & 31;
+            const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+            const int v = at(ix, iy) * w00 + at(ix + 1, iy) * w01 + at(ix, iy + 1) * w10 + at(ix + 1, iy + 1) * w11;
+            dst[(size_t)y * dst_stride + x] = (uint8_t)((v + (1 << 14)) >> 15);
+        }
+    return 0;
+}
+
 }  // extern "C"

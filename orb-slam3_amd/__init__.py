@@ -27,7 +27,7 @@ EXPORTS = [
     "orbx_create", "orbx_destroy", "orbx_last_error", "orbx_max_keypoints", "orbx_extract", "orbx_extract_batch",
     "orbx_extract_batch_async", "orbx_sync", "orbx_result_device", "orbx_result_fetch", "orbx_level_size",
     "orbx_level_image", "orbx_scale_tables", "orbx_features_per_level", "orbx_level_candidates",
-    "orbx_level_selected", "orbx_last_timings", "orbx_mean_timings", "orbx_stream_wait_results", "orbx_stream_wait_other", "orbx_gray_from_color", "orbx_algorithmic_bytes", "orbx_stream", "orbx_dev_alloc",
+    "orbx_level_selected", "orbx_last_timings", "orbx_mean_timings", "orbx_stream_wait_results", "orbx_stream_wait_other", "orbx_gray_from_color", "orbx_remap_linear", "orbx_algorithmic_bytes", "orbx_stream", "orbx_dev_alloc",
     "orbx_dev_free", "orbx_memcpy_h2d", "orbx_memcpy_d2h", "orbx_device_count",
     # include/orbm.h
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_sync", "orbm_stream", "orbm_hamming",
@@ -75,6 +75,7 @@ def lib():
         L.orbx_mean_timings.argtypes = [vp, vp, i32p]
         L.orbx_stream_wait_results.argtypes = [vp, vp]
         L.orbx_stream_wait_other.argtypes = [vp, vp]
+        L.orbx_remap_linear.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int]
         L.orbx_gray_from_color.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
         L.orbx_stream.restype = vp
         L.orbx_stream.argtypes = [vp]
@@ -233,6 +234,25 @@ class ORBextractor:
         _chk(self.L.orbx_gray_from_color(self.h, srcs, HOST, len(imgs), w, h, w * ch, ch, 1 if blue_first else 0, int(coef_bits), dsts, stride),
              "orbx_gray_from_color")
         return buf, stride
+
+    def remap_linear(self, images, mapx, mapy):
+        """cv::remap(img, M1, M2, INTER_LINEAR) of equal-size uint8 host images on the GPU (stereo_euroc.cc:168-169).
+        Returns (DeviceBuffer, stride) with the rectified images back to back."""
+        imgs = [np.ascontiguousarray(i, np.uint8) for i in images]
+        sh, sw = imgs[0].shape
+        mx = np.ascontiguousarray(mapx, np.float32); my = np.ascontiguousarray(mapy, np.float32)
+        dh, dw = mx.shape
+        sstride = (sw + 63) // 64 * 64; dstride = (dw + 63) // 64 * 64
+        src = DeviceBuffer(sstride * sh * len(imgs)); dst = DeviceBuffer(dstride * dh * len(imgs))
+        pad = np.zeros((sh, sstride), np.uint8)
+        for k, im in enumerate(imgs):
+            pad[:, :sw] = im
+            src.upload(pad, offset=k * sstride * sh)
+        dmx = DeviceBuffer(mx.nbytes).upload(mx); dmy = DeviceBuffer(my.nbytes).upload(my)
+        sp = (C.c_void_p * len(imgs))(*[src.ptr + k * sstride * sh for k in range(len(imgs))])
+        dp = (C.c_void_p * len(imgs))(*[dst.ptr + k * dstride * dh for k in range(len(imgs))])
+        _chk(self.L.orbx_remap_linear(self.h, sp, len(imgs), sw, sh, sstride, dmx.ptr, dmy.ptr, dw, dh, dp, dstride), "orbx_remap_linear")
+        return dst, dstride
 
     def enqueue_device(self, dev_ptrs, w, h, stride, lapping=None):
         """dev_ptrs: ctypes array of device pointers; enqueue only (bench hot loop)."""

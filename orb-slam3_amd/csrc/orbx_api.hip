@@ -852,6 +852,27 @@ int orbx_gray_from_color(orbx_t* o, const uint8_t* const* src, int src_space, in
     return rc;
 }
 
+int orbx_remap_linear(orbx_t* o, const uint8_t* const* src, int nimg, int sw, int sh, int src_stride, const float* mapx, const float* mapy,
+                      int dw, int dh, uint8_t* const* dst, int dst_stride) {
+    if (!o || !src || !dst || !mapx || !mapy || nimg < 1 || sw < 1 || sh < 1 || dw < 1 || dh < 1 || src_stride < sw || dst_stride < dw) return ORBX_E_INVALID;
+    for (int i = 0; i < nimg; ++i) if (!src[i] || !dst[i]) return ORBX_E_EMPTY;
+    HIPCHK(hipSetDevice(o->device));
+    hipStream_t st = o->stream;
+    const u8** dS = nullptr; u8** dD = nullptr;
+    int rc = ORBX_OK;
+    do {
+        if (hipMalloc((void**)&dS, sizeof(u8*) * nimg) != hipSuccess || hipMalloc((void**)&dD, sizeof(u8*) * nimg) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
+        if (hipMemcpyAsync((void*)dS, src, sizeof(u8*) * nimg, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync((void*)dD, dst, sizeof(u8*) * nimg, hipMemcpyHostToDevice, st) != hipSuccess) { rc = ORBX_E_HIP; set_err("H2D failed"); break; }
+        hipLaunchKernelGGL(k_remap, dim3((dw + 1023) / 1024, dh, nimg), dim3(256), 0, st, dS, sw, sh, src_stride, mapx, mapy, dw, dh, dD, dst_stride);
+        if (hipGetLastError() != hipSuccess) { rc = ORBX_E_HIP; set_err("k_remap launch failed"); break; }
+    } while (0);
+    (void)hipStreamSynchronize(st);                              // the pointer tables are freed below
+    if (dS) (void)hipFree((void*)dS);
+    if (dD) (void)hipFree((void*)dD);
+    return rc;
+}
+
 int64_t orbx_algorithmic_bytes(const orbx_t* o, int64_t* fused_lower_bound) {
     if (!o) return ORBX_E_INVALID;
     if (fused_lower_bound) *fused_lower_bound = o->fusedBytes;

@@ -1576,4 +1576,37 @@ __global__ __launch_bounds__(256) void k_gray(const u8* const* srcs, int w, int 
     else for (int i = 0; i < n; ++i) d[i] = (u8)(out >> (8 * i));
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_remap: cv::remap(..., INTER_LINEAR, BORDER_CONSTANT 0) for 8-bit images with float maps (stereo rectification,
+// Examples/Stereo/stereo_euroc.cc:168-169): OpenCV's fixed point -- cvRound(map*32), 5-bit fractions, weights
+// (32-fx)(32-fy)*32 .., (sum + 2^14) >> 15.  One thread makes 4 destination pixels (one dword store); the taps are
+// gathers (the map is smooth, so neighbouring lanes hit neighbouring lines).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_remap(const u8* const* srcs, int sw, int sh, int sstride, const float* __restrict__ mapx,
+                                               const float* __restrict__ mapy, int dw, int dh, u8* const* dsts, int dstride) {
+    const int frame = blockIdx.z, y = blockIdx.y;
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x0 >= dw || y >= dh) return;
+    const u8* s = srcs[frame];
+    u8* d = dsts[frame] + (size_t)y * dstride + x0;
+    const int n = min(4, dw - x0);
+    u32 out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < n) {
+            const size_t mi = (size_t)y * dw + x0 + i;
+            const int sx = __float2int_rn(mapx[mi] * 32.f), sy = __float2int_rn(mapy[mi] * 32.f);
+            const int ix = sx >> 5, iy = sy >> 5, fx = sx & 31, fy = sy & 31;
+            const bool x0ok = ix >= 0 && ix < sw, x1ok = ix + 1 >= 0 && ix + 1 < sw, y0ok = iy >= 0 && iy < sh, y1ok = iy + 1 >= 0 && iy + 1 < sh;
+            const u8* p = s + (size_t)iy * sstride + ix;
+            const int v00 = x0ok && y0ok ? gload8(p) : 0, v01 = x1ok && y0ok ? gload8(p + 1) : 0;
+            const int v10 = x0ok && y1ok ? gload8(p + sstride) : 0, v11 = x1ok && y1ok ? gload8(p + sstride + 1) : 0;
+            const int v = v00 * ((32 - fx) * (32 - fy) * 32) + v01 * (fx * (32 - fy) * 32) + v10 * ((32 - fx) * fy * 32) + v11 * (fx * fy * 32);
+            out |= (u32)((v + (1 << 14)) >> 15) << (8 * i);
+        }
+    }
+    if (n == 4 && (((size_t)d) & 3) == 0) *(u32*)d = out;
+    else for (int i = 0; i < n; ++i) d[i] = (u8)(out >> (8 * i));
+}
+
 }  // namespace orbxk

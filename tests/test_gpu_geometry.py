@@ -124,3 +124,38 @@ def test_gray_then_extract_matches_gray_input(pkg, oracle, synth):
         assert mono == mono_ref and kps.tobytes() == kps_ref.tobytes() and np.array_equal(desc, desc_ref)
     finally:
         ex.close()
+
+
+def _rectify_maps(w, h, seed):
+    """Smooth synthetic rectification maps (a mild radial + shear warp around the identity), partly leaving the image."""
+    rng = np.random.default_rng(seed)
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float32)
+    cx, cy = w * 0.5, h * 0.5
+    r2 = ((xs - cx) ** 2 + (ys - cy) ** 2) / (cx * cx + cy * cy)
+    k = np.float32(rng.uniform(-0.08, 0.08))
+    mx = (cx + (xs - cx) * (1 + k * r2) + np.float32(rng.uniform(-3, 3)) + 0.01 * (ys - cy)).astype(np.float32)
+    my = (cy + (ys - cy) * (1 + k * r2) + np.float32(rng.uniform(-3, 3))).astype(np.float32)
+    return mx, my
+
+
+@pytest.mark.parametrize("size", [(752, 480), (101, 37), (5, 3)])
+def test_remap_linear_bit_exact(pkg, oracle, synth, size):
+    """SURVEY 8(f).4 stereo rectification: cv::remap INTER_LINEAR (stereo_euroc.cc:168-169) vs the restated OpenCV fixed point."""
+    w, h = size
+    imgs = [synth.gen_image(max(w, 96), max(h, 96), 40 + k)[:h, :w] for k in range(2)]
+    mx, my = _rectify_maps(w, h, w + h)
+    ex = pkg.ORBextractor(500, max_size=(752, 480), max_batch=2)
+    try:
+        buf, stride = ex.remap_linear(imgs, mx, my)
+        for k, im in enumerate(imgs):
+            got = buf.download(np.uint8, stride * h, offset=k * stride * h).reshape(h, stride)[:, :w]
+            exp = oracle.remap_linear(im, mx, my)
+            assert np.array_equal(got, exp)
+        # identity maps reproduce the image; maps far outside read the constant border 0
+        ys, xs = np.mgrid[0:h, 0:w].astype(np.float32)
+        buf, stride = ex.remap_linear(imgs[:1], xs, ys)
+        assert np.array_equal(buf.download(np.uint8, stride * h).reshape(h, stride)[:, :w], imgs[0])
+        buf, stride = ex.remap_linear(imgs[:1], xs + 10000.0, ys)
+        assert not buf.download(np.uint8, stride * h).reshape(h, stride)[:, :w].any()
+    finally:
+        ex.close()

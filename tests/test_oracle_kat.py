@@ -222,3 +222,15 @@ def test_gray_from_color_known_answers(oracle):
         assert list(oracle.gray_from_color(img, True, bits)[0]) == [exp_rgb[0], exp_rgb[3], exp_rgb[2], exp_rgb[1]]
         rgba = np.concatenate([img, np.full((1, 4, 1), 77, np.uint8)], axis=-1)
         assert list(oracle.gray_from_color(rgba, False, bits)[0]) == exp_rgb       # alpha ignored
+
+
+def test_remap_linear_known_answers(oracle):
+    """cv::remap fixed point: identity, half-pixel average with round-half-up of the 15-bit sum, zero border."""
+    img = np.array([[10, 20, 30], [40, 50, 60]], np.uint8)
+    ys, xs = np.mgrid[0:2, 0:3].astype(np.float32)
+    assert np.array_equal(oracle.remap_linear(img, xs, ys), img)
+    half = oracle.remap_linear(img, xs + 0.5, ys)                        # (a + b + 1) >> 1 ; the last column blends with the border 0
+    assert list(half[0]) == [15, 25, 15] and list(half[1]) == [45, 55, 30]
+    assert not oracle.remap_linear(img, xs - 5.0, ys).any()
+    q = oracle.remap_linear(img, xs + 0.25, ys + 0.5)                    # weights 24*16, 8*16 (x32): exact bilinear, then round
+    assert q[0, 0] == (10 * 24 * 16 * 32 + 20 * 8 * 16 * 32 + 40 * 24 * 16 * 32 + 50 * 8 * 16 * 32 + (1 << 14)) >> 15
