@@ -110,6 +110,11 @@ int orbx_gray_from_color(orbx_t*, const uint8_t* const* src, int src_space, int 
  * maps and destination are dw x dh.  Enqueued on the extractor's stream. */
 int orbx_remap_linear(orbx_t*, const uint8_t* const* src, int nimg, int sw, int sh, int src_stride, const float* mapx, const float* mapy,
                       int dw, int dh, uint8_t* const* dst, int dst_stride);
+/* SURVEY 8(f).4  cv::createCLAHE(clip_limit, Size(tiles_x, tiles_y))->apply(im, im) of the TUM-VI examples
+ * (Examples/Monocular/mono_tum_vi.cc:101-109) for 8-bit single-channel DEVICE images (src[i] may equal dst[i]: the tile LUTs
+ * are finished before any pixel is rewritten).  OpenCV 4.x semantics (see oracle/orbref.h: orbref_clahe). */
+int orbx_clahe(orbx_t*, const uint8_t* const* src, int nimg, int w, int h, int src_stride, double clip_limit, int tiles_x, int tiles_y,
+               uint8_t* const* dst, int dst_stride);
 /* algorithmic bytes of the pyramid+FAST pass for one frame of the current geometry */
 int64_t orbx_algorithmic_bytes(const orbx_t*, int64_t* fused_lower_bound);
 void* orbx_stream(const orbx_t*);     /* hipStream_t the kernels are launched on */

@@ -236,6 +236,16 @@ int orbref_gray_from_color(const uint8_t* src, int w, int h, int src_stride, int
 int orbref_remap_linear(const uint8_t* src, int sw, int sh, int src_stride, const float* mapx, const float* mapy,
                         int dw, int dh, uint8_t* dst, int dst_stride);
 
+/* SURVEY 8(f).4  cv::createCLAHE(clip, Size(tx, ty))->apply(src, dst) for CV_8UC1 (Examples/Monocular/mono_tum_vi.cc:101-109),
+ * OpenCV 4.x imgproc/src/clahe.cpp restated: if the size is not a multiple of the tile grid the image is extended to the
+ * right / bottom with BORDER_REFLECT_101 by (tiles - size % tiles); per tile: 256-bin histogram, clip at
+ * max(int(clip * tileArea / 256), 1), excess spread as excess/256 per bin plus the residual in steps of max(256/residual, 1)
+ * from bin 0; LUT = cvRound(cumsum * (255.f / tileArea)); per pixel bilinear blend of the four neighbouring tile LUTs in
+ * float ((l11*xa1 + l12*xa)*ya1 + (l21*xa1 + l22*xa)*ya, no contraction) and cvRound.  Version unpinned (3.x spreads the
+ * residual over the first bins instead) -> parity unpinned. */
+int orbref_clahe(const uint8_t* src, int w, int h, int src_stride, double clip_limit, int tiles_x, int tiles_y,
+                 uint8_t* dst, int dst_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -236,6 +236,19 @@ def gray_from_color(img, blue_first=False, coef_bits=15):
     return out
 
 
+def clahe(img, clip_limit=3.0, tiles=(8, 8)):
+    """cv::createCLAHE(clip_limit, Size(tiles))->apply(img) restated (orbref_clahe, OpenCV 4.x semantics)."""
+    L = lib()
+    L.orbref_clahe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w), np.uint8)
+    rc = L.orbref_clahe(_p(img), w, h, w, float(clip_limit), int(tiles[0]), int(tiles[1]), _p(out), w)
+    if rc:
+        raise RuntimeError("orbref_clahe failed with code %d" % rc)
+    return out
+
+
 def remap_linear(img, mapx, mapy):
     """cv::remap(img, mapx, mapy, INTER_LINEAR), BORDER_CONSTANT 0, restated (orbref_remap_linear)."""
     L = lib()

@@ -998,4 +998,67 @@ int orbref_remap_linear(const uint8_t* src, int sw, int sh, int src_stride, cons
     return 0;
 }
 
+static inline int reflect101_idx(int p, int n) {              // cv::borderInterpolate(BORDER_REFLECT_101)
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+
+int orbref_clahe(const uint8_t* src, int w, int h, int src_stride, double clip_limit, int tiles_x, int tiles_y,
+                 uint8_t* dst, int dst_stride) {
+    if (!src || !dst || w < 1 || h < 1 || tiles_x < 1 || tiles_y < 1) return -2;
+    int ew = w, eh = h;                                         // extended size (clahe.cpp: copyMakeBorder when not divisible)
+    if (w % tiles_x != 0 || h % tiles_y != 0) { ew = w + (tiles_x - w % tiles_x); eh = h + (tiles_y - h % tiles_y); }
+    const int tw = ew / tiles_x, th = eh / tiles_y, area = tw * th;
+    int clip = 0;
+    if (clip_limit > 0.0) { clip = (int)(clip_limit * area / 256); clip = std::max(clip, 1); }
+    const float lutScale = (float)255 / area;
+    std::vector<uint8_t> lut((size_t)tiles_x * tiles_y * 256);
+    for (int ty = 0; ty < tiles_y; ++ty)
+        for (int tx = 0; tx < tiles_x; ++tx) {
+            int hist[256] = {0};
+            for (int y = ty * th; y < (ty + 1) * th; ++y)
+                for (int x = tx * tw; x < (tx + 1) * tw; ++x)
+                    hist[src[(size_t)reflect101_idx(y, h) * src_stride + reflect101_idx(x, w)]]++;
+            if (clip > 0) {
+                int clipped = 0;
+                for (int i = 0; i < 256; ++i) if (hist[i] > clip) { clipped += hist[i] - clip; hist[i] = clip; }
+                const int redistBatch = clipped / 256;
+                int residual = clipped - redistBatch * 256;
+                for (int i = 0; i < 256; ++i) hist[i] += redistBatch;
+                if (residual != 0) {
+                    const int step = std::max(256 / residual, 1);
+                    for (int i = 0; i < 256 && residual > 0; i += step, residual--) hist[i]++;
+                }
+            }
+            int sum = 0;
+            uint8_t* tl = &lut[((size_t)ty * tiles_x + tx) * 256];
+            for (int i = 0; i < 256; ++i) {
+                sum += hist[i];
+                const int v = (int)lrintf((float)sum * lutScale);
+                tl[i] = (uint8_t)std::min(255, std::max(0, v));
+            }
+        }
+    const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+    for (int y = 0; y < h; ++y) {
+        const float tyf = y * inv_th - 0.5f;
+        int ty1 = (int)std::floor(tyf), ty2 = ty1 + 1;
+        const float ya = tyf - ty1, ya1 = 1.0f - ya;
+        ty1 = std::max(ty1, 0); ty2 = std::min(ty2, tiles_y - 1);
+        for (int x = 0; x < w; ++x) {
+            const float txf = x * inv_tw - 0.5f;
+            int tx1 = (int)std::floor(txf), tx2 = tx1 + 1;
+            const float xa = txf - tx1, xa1 = 1.0f - xa;
+            tx1 = std::max(tx1, 0); tx2 = std::min(tx2, tiles_x - 1);
+            const int v = src[(size_t)y * src_stride + x];
+            const float l11 = lut[((size_t)ty1 * tiles_x + tx1) * 256 + v], l12 = lut[((size_t)ty1 * tiles_x + tx2) * 256 + v];
+            const float l21 = lut[((size_t)ty2 * tiles_x + tx1) * 256 + v], l22 = lut[((size_t)ty2 * tiles_x + tx2) * 256 + v];
+            const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+            const int r = (int)lrintf(res);
+            dst[(size_t)y * dst_stride + x] = (uint8_t)std::min(255, std::max(0, r));
+        }
+    }
+    return 0;
+}
+
 }  // extern "C"

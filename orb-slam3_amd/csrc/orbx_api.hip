@@ -873,6 +873,40 @@ int orbx_remap_linear(orbx_t* o, const uint8_t* const* src, int nimg, int sw, in
     return rc;
 }
 
+int orbx_clahe(orbx_t* o, const uint8_t* const* src, int nimg, int w, int h, int src_stride, double clip_limit, int tiles_x, int tiles_y,
+               uint8_t* const* dst, int dst_stride) {
+    if (!o || !src || !dst || nimg < 1 || w < 1 || h < 1 || tiles_x < 1 || tiles_y < 1 || src_stride < w || dst_stride < w) return ORBX_E_INVALID;
+    for (int i = 0; i < nimg; ++i) if (!src[i] || !dst[i]) return ORBX_E_EMPTY;
+    ClaheGeom G;
+    G.w = w; G.h = h; G.tilesX = tiles_x; G.tilesY = tiles_y;
+    int ew = w, eh = h;                                         // clahe.cpp extends to the right / bottom when the size is not a multiple
+    if (w % tiles_x != 0 || h % tiles_y != 0) { ew = w + (tiles_x - w % tiles_x); eh = h + (tiles_y - h % tiles_y); }
+    if (ew > 2 * w - 1 || eh > 2 * h - 1) { set_err("CLAHE tile grid %dx%d too fine for a %dx%d image", tiles_x, tiles_y, w, h); return ORBX_E_UNSUPPORTED; }
+    G.tw = ew / tiles_x; G.th = eh / tiles_y;
+    const int area = G.tw * G.th;
+    G.clip = 0;
+    if (clip_limit > 0.0) { G.clip = (int)(clip_limit * area / 256); G.clip = std::max(G.clip, 1); }
+    G.lutScale = (float)255 / area; G.invTw = 1.0f / G.tw; G.invTh = 1.0f / G.th;
+    HIPCHK(hipSetDevice(o->device));
+    hipStream_t st = o->stream;
+    const u8** dS = nullptr; u8** dD = nullptr; u8* dLut = nullptr;
+    int rc = ORBX_OK;
+    do {
+        if (hipMalloc((void**)&dS, sizeof(u8*) * nimg) != hipSuccess || hipMalloc((void**)&dD, sizeof(u8*) * nimg) != hipSuccess ||
+            hipMalloc((void**)&dLut, (size_t)nimg * tiles_x * tiles_y * 256) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
+        if (hipMemcpyAsync((void*)dS, src, sizeof(u8*) * nimg, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync((void*)dD, dst, sizeof(u8*) * nimg, hipMemcpyHostToDevice, st) != hipSuccess) { rc = ORBX_E_HIP; set_err("H2D failed"); break; }
+        hipLaunchKernelGGL(k_clahe_lut, dim3(tiles_x * tiles_y, nimg), dim3(256), 0, st, dS, src_stride, G, dLut);
+        hipLaunchKernelGGL(k_clahe_apply, dim3((w + 1023) / 1024, h, nimg), dim3(256), 0, st, dS, src_stride, G, dLut, dD, dst_stride);
+        if (hipGetLastError() != hipSuccess) { rc = ORBX_E_HIP; set_err("CLAHE launch failed"); break; }
+    } while (0);
+    (void)hipStreamSynchronize(st);                              // scratch (pointer tables, LUTs) is freed below
+    if (dS) (void)hipFree((void*)dS);
+    if (dD) (void)hipFree((void*)dD);
+    if (dLut) (void)hipFree(dLut);
+    return rc;
+}
+
 int64_t orbx_algorithmic_bytes(const orbx_t* o, int64_t* fused_lower_bound) {
     if (!o) return ORBX_E_INVALID;
     if (fused_lower_bound) *fused_lower_bound = o->fusedBytes;

@@ -1609,4 +1609,91 @@ __global__ __launch_bounds__(256) void k_remap(const u8* const* srcs, int sw, in
     else for (int i = 0; i < n; ++i) d[i] = (u8)(out >> (8 * i));
 }
 
+// ------------------------------------------------------------------------------------------------
+// CLAHE (cv::createCLAHE(clip, Size(tx, ty))->apply, Examples/Monocular/mono_tum_vi.cc:101-109; OpenCV 4.x clahe.cpp).
+// k_clahe_lut: one workgroup per (tile, frame): LDS histogram, clip + redistribution, cumulative sum -> 256-byte LUT.
+// k_clahe_apply: per pixel the float blend of the four neighbouring tile LUTs, in OpenCV's operation order.
+// ------------------------------------------------------------------------------------------------
+struct ClaheGeom { int w, h, tilesX, tilesY, tw, th, clip; float lutScale, invTw, invTh; };
+
+__device__ __forceinline__ int clahe_reflect(int p, int n) {      // BORDER_REFLECT_101 for the right / bottom extension (p < 2n-1)
+    return p < n ? p : 2 * n - 2 - p;
+}
+
+__global__ __launch_bounds__(256) void k_clahe_lut(const u8* const* srcs, int sstride, ClaheGeom G, u8* luts) {
+    __shared__ u32 hist[256];
+    __shared__ u32 wsum[4];
+    __shared__ u32 s_clipped;
+    const int tile = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+    const int tx = tile % G.tilesX, ty = tile / G.tilesX;
+    const u8* s = srcs[frame];
+    hist[tid] = 0;
+    if (tid == 0) s_clipped = 0;
+    __syncthreads();
+    const int area = G.tw * G.th;
+    for (int i = tid; i < area; i += 256) {
+        const int yy = i / G.tw, xx = i - yy * G.tw;
+        const int y = clahe_reflect(ty * G.th + yy, G.h), x = clahe_reflect(tx * G.tw + xx, G.w);
+        atomicAdd(&hist[gload8(s + (size_t)y * sstride + x)], 1u);
+    }
+    __syncthreads();
+    int hv = (int)hist[tid];
+    if (G.clip > 0) {
+        if (hv > G.clip) { atomicAdd(&s_clipped, (u32)(hv - G.clip)); hv = G.clip; }
+        __syncthreads();
+        const int clipped = (int)s_clipped;
+        const int batch = clipped / 256;
+        const int residual = clipped - batch * 256;
+        hv += batch;
+        if (residual != 0) {
+            const int step = max(256 / residual, 1);               // bins 0, step, 2 step, ... get one more until the residual is spent
+            if (tid % step == 0 && tid / step < residual) ++hv;
+        }
+    }
+    // inclusive prefix sum over the 256 bins
+    u32 inc = (u32)hv;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    u32 base = 0;
+    for (int k = 0; k < wv; ++k) base += wsum[k];
+    const int sum = (int)(base + inc);
+    const int v = __float2int_rn((float)sum * G.lutScale);
+    luts[((size_t)frame * G.tilesX * G.tilesY + tile) * 256 + tid] = (u8)min(255, max(0, v));
+}
+
+__global__ __launch_bounds__(256) void k_clahe_apply(const u8* const* srcs, int sstride, ClaheGeom G, const u8* __restrict__ luts,
+                                                     u8* const* dsts, int dstride) {
+    const int frame = blockIdx.z, y = blockIdx.y;
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x0 >= G.w || y >= G.h) return;
+    const u8* s = srcs[frame] + (size_t)y * sstride + x0;
+    u8* d = dsts[frame] + (size_t)y * dstride + x0;
+    const u8* L = luts + (size_t)frame * G.tilesX * G.tilesY * 256;
+    const float tyf = (float)y * G.invTh - 0.5f;
+    int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+    const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+    ty1 = max(ty1, 0); ty2 = min(ty2, G.tilesY - 1);
+    const int n = min(4, G.w - x0);
+    u32 out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < n) {
+            const float txf = (float)(x0 + i) * G.invTw - 0.5f;
+            int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+            const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+            tx1 = max(tx1, 0); tx2 = min(tx2, G.tilesX - 1);
+            const int v = gload8(s + i);
+            const float l11 = (float)L[(ty1 * G.tilesX + tx1) * 256 + v], l12 = (float)L[(ty1 * G.tilesX + tx2) * 256 + v];
+            const float l21 = (float)L[(ty2 * G.tilesX + tx1) * 256 + v], l22 = (float)L[(ty2 * G.tilesX + tx2) * 256 + v];
+            const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+            out |= (u32)min(255, max(0, __float2int_rn(res))) << (8 * i);
+        }
+    }
+    if (n == 4 && (((size_t)d) & 3) == 0) *(u32*)d = out;
+    else for (int i = 0; i < n; ++i) d[i] = (u8)(out >> (8 * i));
+}
+
 }  // namespace orbxk

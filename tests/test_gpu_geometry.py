@@ -159,3 +159,20 @@ def test_remap_linear_bit_exact(pkg, oracle, synth, size):
         assert not buf.download(np.uint8, stride * h).reshape(h, stride)[:, :w].any()
     finally:
         ex.close()
+
+
+@pytest.mark.parametrize("size,tiles,clip", [((512, 512), (8, 8), 3.0), ((752, 480), (8, 8), 3.0), ((101, 37), (8, 8), 3.0),
+                                             ((320, 240), (4, 6), 40.0), ((256, 128), (8, 8), 0.0), ((33, 65), (2, 3), 1.5)])
+def test_clahe_bit_exact(pkg, oracle, synth, size, tiles, clip):
+    """SURVEY 8(f).4: cv::createCLAHE(clip, tiles)->apply (mono_tum_vi.cc:101-109) on the GPU vs the restated OpenCV 4.x CLAHE,
+    including the reflect-101 extension of sizes that are not a multiple of the tile grid and the unclipped (clip 0) variant."""
+    w, h = size
+    imgs = [synth.gen_image(max(w, 96), max(h, 96), 60 + k, "lowcontrast" if k else "textured")[:h, :w] for k in range(2)]
+    ex = pkg.ORBextractor(500, max_size=(752, 480), max_batch=2)
+    try:
+        buf, stride = ex.clahe(imgs, clip, tiles)
+        for k, im in enumerate(imgs):
+            got = buf.download(np.uint8, stride * h, offset=k * stride * h).reshape(h, stride)[:, :w]
+            assert np.array_equal(got, oracle.clahe(im, clip, tiles)), k
+    finally:
+        ex.close()

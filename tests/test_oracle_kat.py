@@ -234,3 +234,18 @@ def test_remap_linear_known_answers(oracle):
     assert not oracle.remap_linear(img, xs - 5.0, ys).any()
     q = oracle.remap_linear(img, xs + 0.25, ys + 0.5)                    # weights 24*16, 8*16 (x32): exact bilinear, then round
     assert q[0, 0] == (10 * 24 * 16 * 32 + 20 * 8 * 16 * 32 + 40 * 24 * 16 * 32 + 50 * 8 * 16 * 32 + (1 << 14)) >> 15
+
+
+def test_clahe_known_answers(oracle):
+    """CLAHE restatement: a tile holding every gray level once has LUT[i] = cvRound((i+1) * 255/256) when unclipped; a constant
+    image maps to one value; clipping at 1 count per bin flattens any histogram to the same (identity-like) LUT."""
+    tile = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    img = np.tile(tile, (2, 2))                                          # 32x32, 2x2 tiles, every tile identical
+    out = oracle.clahe(img, 0.0, (2, 2))
+    lut = np.array([int(np.rint(np.float32(i + 1) * np.float32(255.0 / 256.0))) for i in range(256)], np.uint8)
+    assert np.array_equal(out, lut[img])
+    const = np.full((32, 32), 77, np.uint8)
+    o2 = oracle.clahe(const, 0.0, (2, 2))
+    assert np.all(o2 == 255)                                             # the whole mass sits at or below 77: cumulative = area
+    o3 = oracle.clahe(const, 1e-9, (2, 2))                               # clip limit max(int(..), 1) = 1 -> 255 spread evenly, residual 255 by steps of 1
+    assert len(np.unique(o3)) == 1 and 60 <= int(o3[0, 0]) <= 100        # ~ (77+1)/256 * 255
