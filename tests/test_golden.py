@@ -81,6 +81,8 @@ def test_oracle_reproduces_golden_geometry(oracle):
     _check_geometry(*_geometry_outputs(M, None, g), g)
     assert np.array_equal(oracle.gray_from_color(g["rgb"], False, 14), g["gray14_rgb"])
     assert np.array_equal(oracle.gray_from_color(g["rgb"], True, 15), g["gray15_bgr"])
+    assert np.array_equal(oracle.remap_linear(g["g96"], g["mapx"], g["mapy"]), g["remap"])
+    assert np.array_equal(oracle.clahe(g["g96"], 3.0, (4, 3)), g["clahe"])
 
 
 @pytest.mark.gpu
@@ -93,5 +95,10 @@ def test_gpu_reproduces_golden_geometry(pkg):
             buf, stride = ex.gray_from_color([g["rgb"]], blue_first, bits)
             h, w = g["rgb"].shape[:2]
             assert np.array_equal(buf.download(np.uint8, stride * h).reshape(h, stride)[:, :w], g[key])
+        h, w = g["g96"].shape
+        buf, stride = ex.remap_linear([g["g96"]], g["mapx"], g["mapy"])
+        assert np.array_equal(buf.download(np.uint8, stride * h).reshape(h, stride)[:, :w], g["remap"])
+        buf, stride = ex.clahe([g["g96"]], 3.0, (4, 3))
+        assert np.array_equal(buf.download(np.uint8, stride * h).reshape(h, stride)[:, :w], g["clahe"])
     finally:
         ex.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Writes tests/golden/geometry.npz: inputs + expected outputs of the SURVEY 8(f).2-4 functions (undistort, image bounds,
-frustum/PredictScale, cvtColor) from the CPU ORACLE -- same status as tools/gen_golden.py: the reference has no vectors
+frustum/PredictScale, cvtColor, remap, CLAHE) from the CPU ORACLE -- same status as tools/gen_golden.py: the reference has no vectors
 and cannot be built here, so these pin the oracle against drift (PARITY UNPINNED).  Regenerate with:
     python tools/gen_golden_geometry.py
 """
@@ -31,8 +31,14 @@ mx = (dist * rng.uniform(0.6, 4.0, m)).astype(np.float32); mn = (mx / 3.5).astyp
 lsf = np.float32(np.log(np.float32(1.2)))
 cnt, fr = M.isInFrustum(Pw, nm, mn, mx, R, t, Ow, K, bounds, 47.90639, 0.5, float(lsf), 8)
 rgb = rng.integers(0, 256, (24, 40, 3), dtype=np.uint8)
+synth = importlib.import_module("orb-slam3_amd.synth")
+g96 = synth.gen_image(96, 96, 11)[:50, :70]
+ys, xs = np.mgrid[0:50, 0:70].astype(np.float32)
+mapx = (xs * np.float32(1.03) - np.float32(2.3) + np.float32(0.02) * ys).astype(np.float32)
+mapy = (ys * np.float32(0.97) + np.float32(1.7)).astype(np.float32)
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "geometry.npz"), K=K, D=D, kps=kps, und=und, bounds=bounds,
                     Pw=Pw, normal=nm.astype(np.float32), min_dist=mn, max_dist=mx, R=R, t=t, Ow=Ow, lsf=lsf, cnt=np.int32(cnt),
                     **{"fr_" + k: v for k, v in fr.items()}, rgb=rgb,
-                    gray14_rgb=orbref.gray_from_color(rgb, False, 14), gray15_bgr=orbref.gray_from_color(rgb, True, 15))
+                    gray14_rgb=orbref.gray_from_color(rgb, False, 14), gray15_bgr=orbref.gray_from_color(rgb, True, 15),
+                    g96=g96, mapx=mapx, mapy=mapy, remap=orbref.remap_linear(g96, mapx, mapy), clahe=orbref.clahe(g96, 3.0, (4, 3)))
 print("wrote geometry.npz: in view", cnt, "of", m)
