@@ -440,6 +440,16 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
             v[p] = make_uint4(0, 0, 0, 0);
             if (ldOk && r < H) v[p] = gload128(src + (size_t)(st.y0 + r) * sp + gx);
         }
+#ifdef F3_ABL_LATENCY2X
+        {   // experiment: a second, data-dependent round trip (same bytes) -- how exposed is the tile-load latency?
+            const u32 z = (u32)qcap >> 30;                      // runtime zero
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+                const int r = (tid >> 5) + p * RP;
+                if (ldOk && r < H) v[p] = gload128(src + (size_t)(st.y0 + r) * sp + gx + (v[p].x & z));
+            }
+        }
+#endif
 #pragma unroll
         for (int p = 0; p < 6; ++p) {
             const int r = (tid >> 5) + p * RP;
