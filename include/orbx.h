@@ -88,6 +88,10 @@ int orbx_level_selected(orbx_t*, int frame, int level, int32_t* xyr, int cap);
  * 5 orient+descriptor, 6 total, 7 wall span from the first resize/FAST launch to the end of the last FAST launch
  * (the two streams overlap, so 0+1 double-counts; 7 is the figure the roofline uses).  ms8 holds 8 floats. */
 int orbx_last_timings(orbx_t*, float* ms8);
+/* stage-boundary events are optional: with `on` = 0 only the dependency events are recorded (a few microseconds less per
+ * batch); orbx_last_timings / orbx_mean_timings then fill ms8[6] (total) and ms8[7] (pyramid+FAST span) and zero the rest.
+ * Default on.  Restarts the timing ring. */
+int orbx_set_stage_timing(orbx_t*, int on);
 /* mean of the same 8 figures over the most recent (<= 32) enqueued batches; *nsamples = how many were averaged.
  * Lets a caller keep enqueueing without a host sync per batch and still report HIP-event kernel times. */
 int orbx_mean_timings(orbx_t*, float* ms8, int* nsamples);

@@ -80,6 +80,7 @@ struct orbx {
     int maxCells = 0;
     KpOut* dKps = nullptr; u8* dDesc = nullptr; KpWork* dWork = nullptr;
     int *dN = nullptr, *dMono = nullptr, *dLap = nullptr, *dErr = nullptr;
+    bool stageTiming = true;                                   // record the stage-boundary events (orbx_set_stage_timing)
     std::vector<const u8*> upPtr; std::vector<int> upLap;      // what dL0Ptr / dLap currently hold
     u32 *dOvf = nullptr, *dOvfList = nullptr;                  // k_fast3 queue overflow list -> k_fast_fix
     size_t capOvfList = 0;
@@ -385,6 +386,9 @@ static int build_geometry(orbx* o, int w, int h) {
     return 0;
 }
 
+// stage-boundary events exist only for the per-stage timings; the dependency / span events (0, 2, 6, 8, 9) are always recorded
+#define STAGE_EV(i, stream) do { if (o->stageTiming) HIPCHK(hipEventRecord(o->ev[i], stream)); } while (0)
+
 extern "C" {
 
 const char* orbx_last_error(void) { return g_err.c_str(); }
@@ -542,7 +546,7 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     hipStream_t s1 = o->serial ? o->stream : o->stream2;          // ORBX_SERIAL=1: single stream, clean per-kernel timings
     HIPCHK(hipEventRecord(o->ev[0], st));
     HIPCHK(hipStreamWaitEvent(s1, o->ev[0], 0));                 // inputs uploaded; previous batch's readers of the pyramid are done
-    HIPCHK(hipEventRecord(o->ev[7], s1));
+    STAGE_EV(7, s1);
     for (int l = 1; l < g.nlevels; ++l) {
         if (o->rzStream[l]) {
             const int nt = (int)o->rzTasks[l].size();
@@ -558,10 +562,10 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     HIPCHK(hipEventRecord(o->ev[8], s1));                        // pyramid ready
     if (o->fastV1) {
         HIPCHK(hipStreamWaitEvent(st, o->ev[8], 0));
-        HIPCHK(hipEventRecord(o->ev[1], st));
+        STAGE_EV(1, st);
         hipLaunchKernelGGL(k_fast, dim3(g.totalCells, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dCells,
                            o->dCandCnt, o->dCandEnt, o->dErr);
-        HIPCHK(hipEventRecord(o->ev[10], st));
+        STAGE_EV(10, st);
     } else {
         // every group waits only for the pyramid levels it reads: the fine levels start while the coarse ones are still
         // being resized (the 7 resizes are a dependent chain of small kernels, ~160 us)
@@ -569,17 +573,17 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
         for (const orbx::F3Group& G : o->f3g) {
             const bool lvl0 = G.lastLevel == 0;
             if (!lvl0) {
-                if (first) HIPCHK(hipEventRecord(o->ev[10], st));   // level-0 FAST done
+                if (first) STAGE_EV(10, st);   // level-0 FAST done
                 HIPCHK(hipStreamWaitEvent(st, G.lastLevel < g.nlevels - 1 ? o->evLvl[G.lastLevel] : o->ev[8], 0));
-                if (first) HIPCHK(hipEventRecord(o->ev[1], st));
+                if (first) STAGE_EV(1, st);
                 first = false;
             }
             hipLaunchKernelGGL(k_fast3, dim3((unsigned)G.nstrips, nimg), dim3(F3_NT), G.lds, st, g, o->dL0Ptr, l0pitch, o->dPyr,
                                o->dCells, o->dStrips + G.strip0, o->dCandCnt, o->dCandEnt, o->dErr, G.tile, G.qcap, o->dOvf, o->dOvfList);
         }
         if (first) {                                             // single-level extractor
-            HIPCHK(hipEventRecord(o->ev[10], st));
-            HIPCHK(hipEventRecord(o->ev[1], st));
+            STAGE_EV(10, st);
+            STAGE_EV(1, st);
         }
         HIPCHK(hipStreamWaitEvent(st, o->ev[8], 0));             // later stages read every level
         hipLaunchKernelGGL(k_fast_fix, dim3(512), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dCells, o->dCandCnt, o->dCandEnt,
@@ -588,7 +592,7 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     HIPCHK(hipEventRecord(o->ev[2], st));
     // blur (VALU + HBM) runs beside the quadtree (LDS-latency bound), not beside FAST (VALU bound)
     if (!o->serial) HIPCHK(hipStreamWaitEvent(s1, o->ev[2], 0));
-    HIPCHK(hipEventRecord(o->ev[11], s1));
+    STAGE_EV(11, s1);
     hipLaunchKernelGGL(k_blur2, dim3((unsigned)(o->tiles.size() + 3) / 4, nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
                        o->dTiles, (int)o->tiles.size(), o->blurSel);
     HIPCHK(hipEventRecord(o->ev[9], s1));                        // blur ready
@@ -604,11 +608,11 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
             hipLaunchKernelGGL(k_quadtree2<256>, dim3(nimg, g.nlevels), dim3(256), o->qt2Lds, st, g2, o->dCandCnt, o->dCandEnt,
                                o->dDense, o->dKpNode, o->dSel, o->dSelCnt, o->dErr, o->maxCells);
     }
-    HIPCHK(hipEventRecord(o->ev[3], st));
+    STAGE_EV(3, st);
     hipLaunchKernelGGL(k_slots, dim3(nimg), dim3(256), 0, st, g, o->dSel, o->dSelCnt, o->dLap, o->dKps, o->dWork, o->dN, o->dMono);
-    HIPCHK(hipEventRecord(o->ev[4], st));
+    STAGE_EV(4, st);
     HIPCHK(hipStreamWaitEvent(st, o->ev[9], 0));
-    HIPCHK(hipEventRecord(o->ev[5], st));
+    STAGE_EV(5, st);
     if (o->odV1)
         hipLaunchKernelGGL(k_orient_desc, dim3((g.kpCap + 3) / 4, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
                            o->dWork, o->dN, o->dKps, o->dDesc, o->dPattern, o->umax);
@@ -758,6 +762,12 @@ int orbx_level_selected(orbx_t* o, int frame, int level, int32_t* xyr, int cap) 
 
 static int timings_of(orbx* o, hipEvent_t* ev, float* ms7) {
     float f0 = 0, f1 = 0;
+    if (!o->stageTiming) {                                   // only the dependency / span events exist: total and pyramid+FAST span
+        for (int i = 0; i < 6; ++i) ms7[i] = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms7[6], ev[0], ev[6]));
+        HIPCHK(hipEventElapsedTime(&ms7[7], ev[0], ev[2]));
+        return ORBX_OK;
+    }
     HIPCHK(hipEventElapsedTime(&ms7[0], ev[7], ev[8]));      // resize chain (stream 2)
     HIPCHK(hipEventElapsedTime(&f0, ev[0], ev[10]));         // FAST level 0 (fastV1: whole FAST is ev1->ev10)
     HIPCHK(hipEventElapsedTime(&f1, ev[1], o->fastV1 ? ev[10] : ev[2]));
@@ -794,6 +804,15 @@ int orbx_mean_timings(orbx_t* o, float* ms8, int* nsamples) {
     }
     for (int i = 0; i < 8; ++i) ms8[i] = n ? (float)(acc[i] / n) : 0.f;
     if (nsamples) *nsamples = n;
+    return ORBX_OK;
+}
+
+int orbx_set_stage_timing(orbx_t* o, int on) {
+    if (!o) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    HIPCHK(hipStreamSynchronize(o->stream)); HIPCHK(hipStreamSynchronize(o->stream2));
+    o->stageTiming = on != 0;
+    o->nEnq = 0; o->timed = false;                            // the ring restarts: sets recorded under the other mode are not mixed in
     return ORBX_OK;
 }
 

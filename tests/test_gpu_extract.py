@@ -167,3 +167,23 @@ def test_fast_queue_overflow_cells_are_redone(pkg, oracle, synth, monkeypatch, q
                 assert mono == mono_ref and kps.tobytes() == kps_ref.tobytes() and np.array_equal(desc, desc_ref)
     finally:
         ex.close()
+
+
+def test_stage_timing_switch(pkg, synth):
+    """orbx_set_stage_timing(0): only the dependency events are recorded; total and pyramid+FAST span stay available."""
+    img = synth.gen_image(752, 480, 3)
+    ex = pkg.ORBextractor(1000, max_size=(752, 480))
+    try:
+        ex(img, (0, 1000))
+        full, n = ex.mean_timings()
+        assert n >= 1 and full["fast"] > 0 and full["blur"] > 0 and full["total"] >= full["pyramid_fast_span"] > 0
+        assert ex.L.orbx_set_stage_timing(ex.h, 0) == 0
+        ex(img, (0, 1000)); ex(img, (0, 1000))
+        lean, n = ex.mean_timings()
+        assert n == 2 and lean["fast"] == 0 and lean["blur"] == 0 and lean["total"] >= lean["pyramid_fast_span"] > 0
+        assert ex.L.orbx_set_stage_timing(ex.h, 1) == 0
+        ex(img, (0, 1000))
+        again, n = ex.mean_timings()
+        assert n == 1 and again["fast"] > 0
+    finally:
+        ex.close()
