@@ -101,16 +101,23 @@ def main():
     sf_host = ex.GetScaleFactors()
     inv_w = float(np.float32(64) / np.float32(W)); inv_h = float(np.float32(48) / np.float32(H))   # Frame.cc:401-402, identity undistortion
 
+    # one handle in flight: the matcher runs on the extractor's stream (batch i's match, then batch i+1's extraction, in order)
+    same_stream = NH == 1
+    if same_stream:
+        assert L.orbm_set_stream(mts[0].h, L.orbx_stream(exs[0].h)) == 0
+
     def step():
         for h in range(NH):
             # the next batch may overwrite result buffers the matcher of the previous step still reads
-            L.orbx_stream_wait_other(exs[h].h, L.orbm_stream(mts[h].h))
+            if not same_stream:
+                L.orbx_stream_wait_other(exs[h].h, L.orbm_stream(mts[h].h))
             if h > 0:
                 L.orbx_stream_wait_other(exs[h].h, L.orbm_stream(mts[h - 1].h))
             exs[h].enqueue_device(ptrs[h], W, H, stride, laps[h])
         for h in range(NH):
             ms = L.orbm_stream(mts[h].h)
-            L.orbx_stream_wait_results(exs[h].h, ms)
+            if not same_stream:
+                L.orbx_stream_wait_results(exs[h].h, ms)
             r = res[h]
             if args.match == "window":
                 # Frame grid (M14) for every frame, then each frame's keypoints search the previous frame inside the

@@ -28,6 +28,9 @@ void orbm_destroy(orbm_t*);
 const char* orbm_last_error(void);
 int orbm_sync(orbm_t*);
 void* orbm_stream(const orbm_t*);
+/* run the matcher's kernels on the caller's hipStream_t (e.g. orbx_stream() of the extractor whose results they read: one
+ * stream, no cross-stream event waits); NULL returns to the handle's own stream */
+int orbm_set_stream(orbm_t*, void* stream);
 
 /* M0  ORBmatcher::DescriptorDistance (ORBmatcher.cc:2911-2931): host-side scalar, 4 x popcount64 */
 int orbm_hamming(const uint8_t* a, const uint8_t* b);

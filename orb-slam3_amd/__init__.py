@@ -30,7 +30,7 @@ EXPORTS = [
     "orbx_level_selected", "orbx_last_timings", "orbx_set_stage_timing", "orbx_mean_timings", "orbx_stream_wait_results", "orbx_stream_wait_other", "orbx_gray_from_color", "orbx_remap_linear", "orbx_clahe", "orbx_algorithmic_bytes", "orbx_stream", "orbx_dev_alloc",
     "orbx_dev_free", "orbx_memcpy_h2d", "orbx_memcpy_d2h", "orbx_device_count",
     # include/orbm.h
-    "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_sync", "orbm_stream", "orbm_hamming",
+    "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_sync", "orbm_stream", "orbm_set_stream", "orbm_hamming",
     "orbm_three_maxima", "orbm_knn2_batch", "orbm_knn2_batch_async", "orbm_last_timing",
 ]
 
@@ -92,6 +92,7 @@ def lib():
         L.orbm_sync.argtypes = [vp]
         L.orbm_stream.restype = vp
         L.orbm_stream.argtypes = [vp]
+        L.orbm_set_stream.argtypes = [vp, vp]
         L.orbm_hamming.argtypes = [vp, vp]
         L.orbm_three_maxima.argtypes = [vp, ci, vp]
         L.orbm_knn2_batch.argtypes = [vp, ci, vp, ci, vp, vp, ci, vp, ci, vp, vp]

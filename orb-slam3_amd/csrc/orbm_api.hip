@@ -26,6 +26,7 @@ static void set_merr(const char* fmt, ...) {
 struct orbm {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t ownStream = nullptr;                           // the stream created with the handle (orbm_set_stream may point `stream` elsewhere)
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     bool timed = false, gridFirst = false;
 };
@@ -45,6 +46,7 @@ int orbm_create(orbm_t** out, int device_id) {
     m->device = device_id;
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->e0) != hipSuccess ||
         hipEventCreate(&m->e1) != hipSuccess || hipEventCreate(&m->e2) != hipSuccess) { set_merr("stream/event creation failed"); orbm_destroy(m); return ORBM_E_HIP; }
+    m->ownStream = m->stream;
     *out = m;
     return ORBM_OK;
 }
@@ -52,7 +54,8 @@ int orbm_create(orbm_t** out, int device_id) {
 void orbm_destroy(orbm_t* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->ownStream) { (void)hipStreamSynchronize(m->ownStream); (void)hipStreamDestroy(m->ownStream); }
     if (m->e0) (void)hipEventDestroy(m->e0);
     if (m->e1) (void)hipEventDestroy(m->e1);
     if (m->e2) (void)hipEventDestroy(m->e2);
@@ -67,6 +70,14 @@ int orbm_sync(orbm_t* m) {
 }
 
 void* orbm_stream(const orbm_t* m) { return m ? (void*)m->stream : nullptr; }
+
+int orbm_set_stream(orbm_t* m, void* stream) {
+    if (!m) return ORBM_E_INVALID;
+    MHIPCHK(hipSetDevice(m->device));
+    MHIPCHK(hipStreamSynchronize(m->stream));
+    m->stream = stream ? (hipStream_t)stream : m->ownStream;
+    return ORBM_OK;
+}
 
 int orbm_hamming(const uint8_t* a, const uint8_t* b) {
     uint64_t x[4], y[4];
