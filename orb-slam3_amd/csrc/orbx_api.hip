@@ -369,6 +369,12 @@ static int build_geometry(orbx* o, int w, int h) {
             if (gi < 2) {
                 const int budget = (160 * 1024 / 7 - 2 * G.tile) / (2 * (F3_NT / 64));
                 G.qcap = std::min(qworst, std::max(512, budget / 64 * 64));
+            } else {
+                // coarse levels: dense corners (over half of a cell's pixels survive on the synthetic stream), so only a mild
+                // bound -- 5 workgroups per CU instead of 4 -- and only if the queue still holds >= 3/4 of the worst case
+                const int budget = (160 * 1024 / 5 - 2 * G.tile) / (2 * (F3_NT / 64));
+                const int q5 = budget / 64 * 64;
+                if (q5 < qworst && q5 * 4 >= qworst * 3) G.qcap = q5;
             }
             if (o->f3QcapForce > 0) G.qcap = std::min(G.qcap, align_up(o->f3QcapForce, 64));
             G.lds = (size_t)2 * G.tile + (size_t)(F3_NT / 64) * G.qcap * 2;
