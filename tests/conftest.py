@@ -12,6 +12,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:                                                    # property tests explore the same examples on every run
+        import hypothesis
+        hypothesis.settings.register_profile("repro", derandomize=True, deadline=None, database=None)
+        hypothesis.settings.load_profile("repro")
+    except ImportError:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -66,6 +66,65 @@ def test_distribute_returns_at_most_n_plus_3_distinct_candidates(oracle, seed, N
     xyr = np.concatenate([pts, rng.integers(7, 200, (len(pts), 1))], 1).astype(np.int32)
     sel = oracle.distribute(xyr, 16, 736, 16, 464, N)
     assert len(set(sel.tolist())) == len(sel) and len(sel) <= max(N + 3, 8)
-    assert len(sel) == min(len(pts), len(sel)) and (len(pts) <= N or len(sel) >= min(N, len(pts)) - 0 or True)
-    if len(pts) <= N:
-        assert len(sel) == len(pts)                              # every candidate ends alone in a node
+    # (not "== len(pts)" when len(pts) <= N: a split whose points all fall into one child leaves the list size unchanged and
+    # ORBextractor.cc:889-895 then stops with two candidates still sharing a node)
+    assert len(sel) <= len(pts)
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(0, 2**31 - 1), st.integers(3, 40), st.integers(3, 30))
+def test_ingest_invariants(oracle, seed, w, h):
+    """cvtColor: gray images stay themselves, channel order only swaps R and B, 14- and 15-bit tables differ by at most 1;
+    remap: the identity map reproduces the image and integer shifts move it (zero border)."""
+    rng = np.random.default_rng(seed)
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    g = rgb[..., 0]
+    ggg = np.stack([g, g, g], axis=-1)
+    for bits in (14, 15):
+        assert np.array_equal(oracle.gray_from_color(ggg, False, bits), g)
+        assert np.array_equal(oracle.gray_from_color(rgb, False, bits), oracle.gray_from_color(rgb[..., ::-1], True, bits))
+    d = oracle.gray_from_color(rgb, False, 14).astype(int) - oracle.gray_from_color(rgb, False, 15).astype(int)
+    assert np.abs(d).max() <= 1
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float32)
+    assert np.array_equal(oracle.remap_linear(g, xs, ys), g)
+    sh = oracle.remap_linear(g, xs + 1.0, ys)
+    assert np.array_equal(sh[:, :-1], g[:, 1:]) and not sh[:, -1].any()
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.integers(0, 2**31 - 1), st.floats(0.5, 8.0))
+def test_clahe_invariants(oracle, seed, clip):
+    """CLAHE: the per-tile mapping is monotone, so the order of gray levels inside a constant-tile image is preserved;
+    output is deterministic and differs from the unclipped equalisation only by a bounded amount of contrast."""
+    rng = np.random.default_rng(seed)
+    tile = rng.integers(0, 256, (16, 16), dtype=np.uint8)
+    img = np.tile(tile, (2, 3))                                          # identical tiles: the blend is the tile's own LUT
+    out = oracle.clahe(img, clip, (3, 2))
+    assert np.array_equal(out, oracle.clahe(img, clip, (3, 2)))
+    flat_in, flat_out = img.ravel().astype(int), out.ravel().astype(int)
+    order = np.argsort(flat_in, kind="stable")
+    assert np.all(np.diff(flat_out[order]) >= 0)                         # monotone LUT
+    same = flat_in[:, None] == flat_in[None, :256]
+    assert all(len(set(flat_out[flat_in == v])) == 1 for v in np.unique(flat_in)[:20])   # one output per input level
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(0, 2**31 - 1))
+def test_undistort_and_frustum_invariants(oracle, pkg, seed):
+    """Undistortion with k1 == 0 is the identity copy; distort-free projection of a point on the optical axis lands on the
+    principal point; a point seen exactly head-on at distance d with maxDistance = d * 1.2^k predicts level k."""
+    rng = np.random.default_rng(seed)
+    M = oracle._oracle_matcher_class()()
+    K = [float(rng.uniform(300, 600)), float(rng.uniform(300, 600)), float(rng.uniform(200, 400)), float(rng.uniform(150, 300))]
+    kps = np.zeros(8, pkg.KP_DTYPE); kps["x"] = rng.uniform(0, 640, 8); kps["y"] = rng.uniform(0, 480, 8)
+    assert M.UndistortKeyPoints(kps, K, [0.0, 0.3, 0.01, 0.01]).tobytes() == kps.tobytes()
+    pp = np.zeros(1, pkg.KP_DTYPE); pp["x"] = np.float32(K[2]); pp["y"] = np.float32(K[3])
+    u = M.UndistortKeyPoints(pp, K, [float(rng.uniform(-0.4, 0.4)), 0.05, 0.001, -0.001])
+    assert u["x"][0] == np.float32(K[2]) and u["y"][0] == np.float32(K[3])
+    k = int(rng.integers(0, 8)); d = float(rng.uniform(1.0, 10.0))
+    lsf = float(np.log(np.float32(1.2)))
+    mx = np.array([d * 1.2 ** k * 0.97], np.float32)                      # ratio a little under 1.2^k: ceil() gives k for k >= 1
+    cnt, o = M.isInFrustum(np.array([[0, 0, d]], np.float32), np.array([[0, 0, 1]], np.float32), np.array([0.01], np.float32), mx,
+                           np.eye(3), np.zeros(3), np.zeros(3), K, [0.0, 2 * K[2], 0.0, 2 * K[3]], 40.0, 0.5, lsf, 8)
+    assert cnt == 1 and o["proj_x"][0] == np.float32(K[2]) and o["proj_y"][0] == np.float32(K[3])
+    assert o["level"][0] == (k if k >= 1 else 0) and o["view_cos"][0] == 1.0
