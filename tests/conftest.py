@@ -15,7 +15,8 @@ def pytest_configure(config):
     try:                                                    # property tests explore the same examples on every run
         import hypothesis
         hypothesis.settings.register_profile("repro", derandomize=True, deadline=None, database=None)
-        hypothesis.settings.load_profile("repro")
+        if not os.environ.get("ORB_HYPOTHESIS_RANDOM"):       # set it to explore fresh examples locally
+            hypothesis.settings.load_profile("repro")
     except ImportError:
         pass
 
