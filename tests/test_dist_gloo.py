@@ -31,7 +31,10 @@ def _worker(rank, world, port, n_frames, q):
 def test_sharding_and_count_gather_world2(n_frames):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + n_frames
+    import socket
+    with socket.socket() as sock:                          # a port that is free right now
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
     for p in procs:
         p.start()
