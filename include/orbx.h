@@ -69,6 +69,9 @@ int orbx_result_device(const orbx_t*, const orbx_kp_t** kps, const uint8_t** des
                        const int32_t** monos, int* cap);
 /* copy image `i` of the last batch to host buffers; returns n or ORBX_E_* */
 int orbx_result_fetch(orbx_t*, int i, orbx_kp_t* kps, uint8_t* desc, int cap, int* mono_index);
+/* all frames of the last batch at once: kps / desc are [nimg][cap_per_img] (one device-to-host copy each when cap_per_img ==
+ * orbx_max_keypoints()); n_out / mono_out [nimg].  Returns nimg. */
+int orbx_result_fetch_all(orbx_t*, orbx_kp_t* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out);
 
 /* mvImagePyramid back-door (include/ORBextractor.h:83; used by Frame::ComputeStereoMatches, Frame.cc:1168) */
 int orbx_level_size(const orbx_t*, int level, int* w, int* h);

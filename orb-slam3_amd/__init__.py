@@ -25,7 +25,7 @@ TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30          # ORBmatcher.cc:36-38
 EXPORTS = [
     # include/orbx.h
     "orbx_create", "orbx_destroy", "orbx_last_error", "orbx_max_keypoints", "orbx_extract", "orbx_extract_batch",
-    "orbx_extract_batch_async", "orbx_sync", "orbx_result_device", "orbx_result_fetch", "orbx_level_size",
+    "orbx_extract_batch_async", "orbx_sync", "orbx_result_device", "orbx_result_fetch", "orbx_result_fetch_all", "orbx_level_size",
     "orbx_level_image", "orbx_scale_tables", "orbx_features_per_level", "orbx_level_candidates",
     "orbx_level_selected", "orbx_last_timings", "orbx_set_stage_timing", "orbx_mean_timings", "orbx_stream_wait_results", "orbx_stream_wait_other", "orbx_gray_from_color", "orbx_remap_linear", "orbx_clahe", "orbx_algorithmic_bytes", "orbx_stream", "orbx_dev_alloc",
     "orbx_dev_free", "orbx_memcpy_h2d", "orbx_memcpy_d2h", "orbx_device_count",
@@ -63,6 +63,7 @@ def lib():
         L.orbx_sync.argtypes = [vp]
         L.orbx_result_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32p]
         L.orbx_result_fetch.argtypes = [vp, ci, vp, vp, ci, i32p]
+        L.orbx_result_fetch_all.argtypes = [vp, vp, vp, ci, vp, vp]
         L.orbx_level_size.argtypes = [vp, ci, i32p, i32p]
         L.orbx_level_image.argtypes = [vp, ci, ci, ci, vp, ci]
         L.orbx_scale_tables.argtypes = [vp, vp, vp, vp, vp]
@@ -223,7 +224,16 @@ class ORBextractor:
         n_out = np.zeros(len(imgs), np.int32); m_out = np.zeros(len(imgs), np.int32)
         _chk(self.L.orbx_extract_batch(self.h, ptrs, HOST, len(imgs), w, h, w, None if lap is None else _p(lap),
                                        _p(n_out), _p(m_out)), "orbx_extract_batch")
-        return [self.fetch(i) for i in range(len(imgs))]
+        return self.fetch_all()
+
+    def fetch_all(self):
+        """Results of every frame of the last batch with one device-to-host copy per array."""
+        B = self.L.orbx_result_fetch_all(self.h, None, None, self.cap, None, None)
+        _chk(B, "orbx_result_fetch_all")
+        kps = np.zeros((B, self.cap), KP_DTYPE); desc = np.zeros((B, self.cap, 32), np.uint8)
+        n = np.zeros(B, np.int32); m = np.zeros(B, np.int32)
+        _chk(self.L.orbx_result_fetch_all(self.h, _p(kps), _p(desc), self.cap, _p(n), _p(m)), "orbx_result_fetch_all")
+        return [(int(m[i]), kps[i, :n[i]].copy(), desc[i, :n[i]].copy()) for i in range(B)]
 
     def gray_from_color(self, images, blue_first=False, coef_bits=15):
         """cv::cvtColor(..., COLOR_*2GRAY) of equal-size HxWx{3,4} uint8 host images on the GPU (Tracking.cc:1264-1290).

@@ -81,6 +81,8 @@ struct orbx {
     KpOut* dKps = nullptr; u8* dDesc = nullptr; KpWork* dWork = nullptr;
     int *dN = nullptr, *dMono = nullptr, *dLap = nullptr, *dErr = nullptr;
     bool stageTiming = true;                                   // record the stage-boundary events (orbx_set_stage_timing)
+    std::vector<int> hN, hMono; bool countsValid = false;      // per-frame counts of the last batch, fetched once
+    u8* hPinned = nullptr; size_t capPinned = 0; hipEvent_t evH2D = nullptr;   // pinned staging of host images
     std::vector<const u8*> upPtr; std::vector<int> upLap;      // what dL0Ptr / dLap currently hold
     u32 *dOvf = nullptr, *dOvfList = nullptr;                  // k_fast3 queue overflow list -> k_fast_fix
     size_t capOvfList = 0;
@@ -489,6 +491,8 @@ void orbx_destroy(orbx_t* o) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& set : o->evr) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     if (o->evDone) (void)hipEventDestroy(o->evDone);
+    if (o->evH2D) (void)hipEventDestroy(o->evH2D);
+    if (o->hPinned) (void)hipHostFree(o->hPinned);
     for (auto& e : o->evLvl) if (e) (void)hipEventDestroy(e);
     if (o->stream) (void)hipStreamDestroy(o->stream);
     if (o->stream2) (void)hipStreamDestroy(o->stream2);
@@ -523,11 +527,25 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
         }
         l0pitch = o->l0pitch;
     } else {
-        for (int i = 0; i < nimg; ++i) {
-            u8* d = o->dL0 + (size_t)i * o->l0pitch * h;
-            HIPCHK(hipMemcpy2DAsync(d, o->l0pitch, imgs[i], stride, w, h, hipMemcpyHostToDevice, st));
-            o->hL0Ptr[i] = d;
+        // host images: packed into one pinned staging buffer (CPU memcpy), then ONE asynchronous copy for the whole batch --
+        // per-image copies from pageable memory run at ~3 GB/s and block the calling thread
+        const size_t imgBytes = (size_t)o->l0pitch * h, need = imgBytes * nimg;
+        if (need > o->capPinned) {
+            if (o->hPinned) (void)hipHostFree(o->hPinned);
+            o->hPinned = nullptr; o->capPinned = 0;
+            HIPCHK(hipHostMalloc((void**)&o->hPinned, need, hipHostMallocDefault));
+            o->capPinned = need;
         }
+        if (!o->evH2D) HIPCHK(hipEventCreateWithFlags(&o->evH2D, hipEventDisableTiming));
+        else HIPCHK(hipEventSynchronize(o->evH2D));               // the previous batch's DMA out of the staging buffer is done
+        for (int i = 0; i < nimg; ++i) {
+            u8* p = o->hPinned + imgBytes * i;
+            if (stride == o->l0pitch) memcpy(p, imgs[i], (size_t)stride * h);
+            else for (int y = 0; y < h; ++y) memcpy(p + (size_t)y * o->l0pitch, imgs[i] + (size_t)y * stride, (size_t)w);
+            o->hL0Ptr[i] = o->dL0 + imgBytes * i;
+        }
+        HIPCHK(hipMemcpyAsync(o->dL0, o->hPinned, need, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(o->evH2D, st));
         l0pitch = o->l0pitch;
     }
     for (int i = 0; i < nimg; ++i) { o->hLap[2 * i] = lap01 ? lap01[2 * i] : 0; o->hLap[2 * i + 1] = lap01 ? lap01[2 * i + 1] : 0; }
@@ -629,6 +647,7 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     HIPCHK(hipGetLastError());
     o->lastBatch = nimg;
     o->timed = true;
+    o->countsValid = false;
     return ORBX_OK;
 }
 
@@ -643,14 +662,28 @@ int orbx_sync(orbx_t* o) {
     return ORBX_OK;
 }
 
+// one sync + error check + two small copies per BATCH (not per frame): the counts every fetch needs
+static int fetch_counts(orbx* o) {
+    if (o->countsValid) return ORBX_OK;
+    int rc = orbx_sync(o);
+    if (rc) return rc;
+    o->hN.resize(o->lastBatch); o->hMono.resize(o->lastBatch);
+    if (o->lastBatch > 0) {
+        HIPCHK(hipMemcpy(o->hN.data(), o->dN, sizeof(int) * o->lastBatch, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(o->hMono.data(), o->dMono, sizeof(int) * o->lastBatch, hipMemcpyDeviceToHost));
+    }
+    o->countsValid = true;
+    return ORBX_OK;
+}
+
 int orbx_extract_batch(orbx_t* o, const uint8_t* const* imgs, int img_space, int nimg, int w, int h, int stride,
                        const int* lap01, int* n_out, int* mono_out) {
     int rc = orbx_extract_batch_async(o, imgs, img_space, nimg, w, h, stride, lap01);
     if (rc) return rc;
-    rc = orbx_sync(o);
+    rc = fetch_counts(o);
     if (rc) return rc;
-    if (n_out) HIPCHK(hipMemcpy(n_out, o->dN, sizeof(int) * nimg, hipMemcpyDeviceToHost));
-    if (mono_out) HIPCHK(hipMemcpy(mono_out, o->dMono, sizeof(int) * nimg, hipMemcpyDeviceToHost));
+    if (n_out) memcpy(n_out, o->hN.data(), sizeof(int) * nimg);
+    if (mono_out) memcpy(mono_out, o->hMono.data(), sizeof(int) * nimg);
     return ORBX_OK;
 }
 
@@ -668,11 +701,9 @@ int orbx_result_device(const orbx_t* o, const orbx_kp_t** kps, const uint8_t** d
 int orbx_result_fetch(orbx_t* o, int i, orbx_kp_t* kps, uint8_t* desc, int cap, int* mono_index) {
     if (!o || i < 0 || i >= o->lastBatch) return ORBX_E_INVALID;
     HIPCHK(hipSetDevice(o->device));
-    int rc = orbx_sync(o);
+    int rc = fetch_counts(o);
     if (rc) return rc;
-    int n = 0, mono = 0;
-    HIPCHK(hipMemcpy(&n, o->dN + i, sizeof(int), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&mono, o->dMono + i, sizeof(int), hipMemcpyDeviceToHost));
+    const int n = o->hN[i], mono = o->hMono[i];
     if (n > cap) { set_err("%d keypoints exceed caller capacity %d", n, cap); return ORBX_E_CAPACITY; }
     if (n > 0) {
         if (kps) HIPCHK(hipMemcpy(kps, o->dKps + (size_t)i * o->g.kpCap, sizeof(KpOut) * n, hipMemcpyDeviceToHost));
@@ -680,6 +711,26 @@ int orbx_result_fetch(orbx_t* o, int i, orbx_kp_t* kps, uint8_t* desc, int cap, 
     }
     if (mono_index) *mono_index = mono;
     return n;
+}
+
+int orbx_result_fetch_all(orbx_t* o, orbx_kp_t* kps, uint8_t* desc, int cap_per_img, int* n_out, int* mono_out) {
+    if (!o || o->lastBatch < 1 || cap_per_img < 1) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    int rc = fetch_counts(o);
+    if (rc) return rc;
+    const int B = o->lastBatch, dc = o->g.kpCap;
+    for (int i = 0; i < B; ++i) if (o->hN[i] > cap_per_img) { set_err("%d keypoints exceed caller capacity %d", o->hN[i], cap_per_img); return ORBX_E_CAPACITY; }
+    if (cap_per_img == dc) {                                    // same layout as the device buffers: one copy each
+        if (kps) HIPCHK(hipMemcpy(kps, o->dKps, sizeof(KpOut) * (size_t)dc * B, hipMemcpyDeviceToHost));
+        if (desc) HIPCHK(hipMemcpy(desc, o->dDesc, (size_t)32 * dc * B, hipMemcpyDeviceToHost));
+    } else {
+        const size_t rows = (size_t)std::min(cap_per_img, dc);
+        if (kps) HIPCHK(hipMemcpy2D(kps, sizeof(KpOut) * cap_per_img, o->dKps, sizeof(KpOut) * dc, sizeof(KpOut) * rows, B, hipMemcpyDeviceToHost));
+        if (desc) HIPCHK(hipMemcpy2D(desc, (size_t)32 * cap_per_img, o->dDesc, (size_t)32 * dc, 32 * rows, B, hipMemcpyDeviceToHost));
+    }
+    if (n_out) memcpy(n_out, o->hN.data(), sizeof(int) * B);
+    if (mono_out) memcpy(mono_out, o->hMono.data(), sizeof(int) * B);
+    return B;
 }
 
 int orbx_extract(orbx_t* o, const uint8_t* img, int w, int h, int stride, int lap0, int lap1,
