@@ -187,3 +187,27 @@ def test_stage_timing_switch(pkg, synth):
         assert n == 1 and again["fast"] > 0
     finally:
         ex.close()
+
+
+def test_result_fetch_all_layouts(pkg, oracle, synth):
+    """orbx_result_fetch_all: one copy per array at the device capacity, strided copies at any other caller capacity, and the
+    capacity error when a frame does not fit."""
+    import ctypes as C
+    imgs = [synth.gen_image(752, 480, 70 + i) for i in range(3)]
+    ref = [oracle.Extractor(1000)(im, (0, 1000)) for im in imgs]
+    ex = pkg.ORBextractor(1000, max_size=(752, 480), max_batch=3)
+    try:
+        out = ex.extract_batch(imgs, [(0, 1000)] * 3)                    # fetch_all at cap == orbx_max_keypoints
+        for (mono, kps, desc), (n0, k0, d0, m0) in zip(out, ref):
+            assert mono == m0 and kps.tobytes() == k0.tobytes() and np.array_equal(desc, d0)
+        for cap in (ex.cap + 17, max(r[0] for r in ref)):
+            kps = np.zeros((3, cap), pkg.KP_DTYPE); desc = np.zeros((3, cap, 32), np.uint8)
+            n = np.zeros(3, np.int32); m = np.zeros(3, np.int32)
+            rc = ex.L.orbx_result_fetch_all(ex.h, kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), cap,
+                                            n.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p))
+            assert rc == 3
+            for i, (n0, k0, d0, m0) in enumerate(ref):
+                assert n[i] == n0 and m[i] == m0 and kps[i, :n0].tobytes() == k0.tobytes() and np.array_equal(desc[i, :n0], d0)
+        assert ex.L.orbx_result_fetch_all(ex.h, None, None, 10, None, None) < 0      # 10 keypoints per frame are not enough
+    finally:
+        ex.close()
