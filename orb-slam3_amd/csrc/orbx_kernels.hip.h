@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int 
             // rows past the block are clamped, not skipped: no zero-initialised destination, no branch (their sums are never used)
             const int r = min(r0 + k, nrows - 1);
             const int ys = reflect101(t.y0 - 3 + r, h);
-            Bn[k] = gload32u(im + (size_t)ys * sp, (u32)gcl * 4u);           // uniform row base + per-lane byte offset
+            Bn[k] = gload32u(im, (u32)(ys * sp) + (u32)gcl * 4u);            // 32-bit offset from the level base (one s_mul, one v_add)
         }
     };
     fetch(0);
@@ -1312,7 +1312,7 @@ __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int 
                         acc[i] = __builtin_amdgcn_udot2(as_us2(Q[k][i]), KD, a, false);
                     }
                     const u32 packed = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u) | __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
-                    if (doStore) gstore32u(dst + (size_t)(t.y0 + r - 6) * L.pitch, (u32)gc * 4u, packed);
+                    if (doStore) gstore32u(dst, (u32)((t.y0 + r - 6) * L.pitch) + (u32)gc * 4u, packed);
                 }
             }
         }
