@@ -80,11 +80,15 @@ __device__ __forceinline__ uint2 gload64u_unaligned(const void* base, u32 off) {
     const unsigned long long v = *(const __attribute__((address_space(1))) u64a1*)((const __attribute__((address_space(1))) u8*)base + off);
     return make_uint2((u32)v, (u32)(v >> 32));
 }
+__device__ __forceinline__ uint4 gload128u(const void* base, u32 off) {
+    return *(const __attribute__((address_space(1))) uint4*)((const __attribute__((address_space(1))) u8*)base + off);
+}
 __device__ __forceinline__ u32 gload32(const void* p) { return *(const __attribute__((address_space(1))) u32*)p; }
 __device__ __forceinline__ uint4 gload128(const void* p) { return *(const __attribute__((address_space(1))) uint4*)p; }
 __device__ __forceinline__ u8 gload8(const void* p) { return *(const __attribute__((address_space(1))) u8*)p; }
 #else
 __device__ __forceinline__ u32 gload32u(const void* base, u32 off) { return *(const u32*)((const u8*)base + off); }
+__device__ __forceinline__ uint4 gload128u(const void* base, u32 off) { return *(const uint4*)((const u8*)base + off); }
 __device__ __forceinline__ uint2 gload64u_unaligned(const void* base, u32 off) { uint2 r; __builtin_memcpy(&r, (const u8*)base + off, 8); return r; }
 __device__ __forceinline__ void gstore32u(void* base, u32 off, u32 v) { *(u32*)((u8*)base + off) = v; }
 __device__ __forceinline__ u32 gload32(const void* p) { return *(const u32*)p; }
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, in
 #pragma unroll
     for (int j = 0; j < RZ_SRC; ++j) {
         d[j] = make_uint2(0, 0);
-        if (j < nsrc) d[j] = gload64u_unaligned(src + (size_t)(sFirst + j) * sp, colo);   // wave-uniform row base, per-lane offset
+        if (j < nsrc) d[j] = gload64u_unaligned(src, (u32)((sFirst + j) * sp) + colo);     // level base + 32-bit offset (row part is wave-uniform)
     }
     int Hp[4] = {0, 0, 0, 0};
     int dy = y0;
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, in
                         const u32 v = (((u32)__mul24(ty.a0, Hp[i]) >> 16) + ((u32)__mul24(ty.a1, Hc[i]) >> 16) + 2u) >> 2;
                         packed |= v << (8 * i);
                     }
-                    if (act) gstore32u(dst + (size_t)dy * D.pitch, (u32)gcol * 4u, packed);
+                    if (act) gstore32u(dst, (u32)(dy * D.pitch) + (u32)gcol * 4u, packed);
                     ++dy;
                 }
             }
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
         for (int p = 0; p < 6; ++p) {
             const int r = (tid >> 5) + p * RP;
             v[p] = make_uint4(0, 0, 0, 0);
-            if (ldOk && r < H) v[p] = gload128(src + (size_t)(st.y0 + r) * sp + gx);
+            if (ldOk && r < H) v[p] = gload128u(src, (u32)(__mul24(st.y0 + r, sp) + gx));
         }
 #ifdef F3_ABL_LATENCY2X
         {   // experiment: a second, data-dependent round trip (same bytes) -- how exposed is the tile-load latency?
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
         for (int r = (tid >> 5) + 6 * RP; r < H; r += RP) {               // taller cells (tiny images only)
             if (colOk) {
                 uint4 t = make_uint4(0, 0, 0, 0);
-                if (gx < rowLimit) t = gload128(src + (size_t)(st.y0 + r) * sp + gx);
+                if (gx < rowLimit) t = gload128u(src, (u32)(__mul24(st.y0 + r, sp) + gx));
                 *(uint4*)(img + r * Pb + ck * 16) = t;
                 *(uint4*)(sc + r * Pb + ck * 16) = make_uint4(0, 0, 0, 0);
             }
