@@ -1,16 +1,22 @@
 """GPU parity of the flattened ORBmatcher searches (GPU distance phase + host replay) vs the CPU oracle's
 reference-structured restatements.  Everything compared is integer / index work -> bit-exact; the stereo outputs
 (uright, depth) are floats produced by the same expression sequence and are compared bit-for-bit as well."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def scene(pkg, oracle, synth):
+# ORB_SCENE_SEEDS=100,101,... repeats every test of this module on more synthetic scenes (a wider parity sweep on the GPU box)
+_SEEDS = [int(x) for x in os.environ.get("ORB_SCENE_SEEDS", "100").split(",")]
+
+
+@pytest.fixture(scope="module", params=_SEEDS)
+def scene(request, pkg, oracle, synth):
     """Two views (synthetic rectified stereo pair) extracted on the GPU, plus oracle extractors holding the same pyramids."""
-    l, r = synth.gen_stereo_pair(752, 480, 100)
+    l, r = synth.gen_stereo_pair(752, 480, request.param)
     exl = pkg.ORBextractor(1200, max_size=(752, 480)); exr = pkg.ORBextractor(1200, max_size=(752, 480))
     _, kl, dl = exl(l, (0, 0)); _, kr, dr = exr(r, (0, 0))
     ol, orr = oracle.Extractor(1200), oracle.Extractor(1200)
