@@ -417,7 +417,7 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
     extern __shared__ __attribute__((aligned(16))) unsigned char f3smem[];
     u8* img = f3smem;
     u8* sc = f3smem + tileBytes;
-    StripInfo st = strips[blockIdx.x];
+    StripInfo st = strips[gridDim.x - 1 - blockIdx.x];                // coarser (denser, slower) strips of the group first: a lighter tail
     st.level = (short)__builtin_amdgcn_readfirstlane(st.level);
     const int frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);              // wave-uniform: per-cell metadata comes through the scalar cache
