@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborbslam3_amd.so")
+LIB_PATH = os.environ.get("ORB_LIB") or os.path.join(_HERE, "liborbslam3_amd.so")   # ORB_LIB: A/B builds of the same ABI
 _LIB = None
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
