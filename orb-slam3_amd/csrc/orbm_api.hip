@@ -29,6 +29,11 @@ struct orbm {
     hipStream_t ownStream = nullptr;                           // the stream created with the handle (orbm_set_stream may point `stream` elsewhere)
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     bool timed = false, gridFirst = false;
+    // Scratch arena of the single-frame entry points: ONE device block and a pinned host mirror of the same size.  Uploads are
+    // staged in the mirror and sent with one asynchronous copy before the kernel, results come back with one copy after it
+    // (a dozen hipMalloc / small pageable copies per call cost over a millisecond).
+    uint8_t* arDev = nullptr; uint8_t* arPin = nullptr;
+    size_t arCap = 0, arOff = 0, arUp = 0, arOutLo = (size_t)-1, arOutHi = 0;   // bump offset; [0, arUp) staged uploads; small outputs in [arOutLo, arOutHi)
 };
 
 extern "C" {
@@ -56,6 +61,8 @@ void orbm_destroy(orbm_t* m) {
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->ownStream) { (void)hipStreamSynchronize(m->ownStream); (void)hipStreamDestroy(m->ownStream); }
+    if (m->arDev) (void)hipFree(m->arDev);
+    if (m->arPin) (void)hipHostFree(m->arPin);
     if (m->e0) (void)hipEventDestroy(m->e0);
     if (m->e1) (void)hipEventDestroy(m->e1);
     if (m->e2) (void)hipEventDestroy(m->e2);
@@ -164,15 +171,50 @@ extern "C" int orbx_internal_levels(void* o, int frame, int* nlevels, const uint
 
 namespace {
 
-struct DevBuf {                                              // RAII device allocation + upload helpers
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4) == hipSuccess; }
-    bool upload(const void* src, size_t bytes) { return alloc(bytes) && (bytes == 0 || hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) == hipSuccess); }
-    template <class T> T* as() { return (T*)p; }
+// Arena sub-allocations.  A DevBuf is an (offset, size) view, resolved against the arena's current blocks when used, so the
+// arena may grow (reallocate) while a function is still collecting its buffers.  Protocol inside one entry point:
+//   arena_reset(m); UP(...) / AL(...) for every buffer (uploads first); ARENA_FLUSH(m); launch; sync; ARENA_FETCH(m); read .host()
+struct DevBuf {
+    orbm* m = nullptr; size_t off = 0, bytes = 0; bool ok = false;
+    template <class T> T* as() { return ok ? (T*)(m->arDev + off) : nullptr; }
+    void* ptr() { return as<void>(); }
+    const void* host() const { return m->arPin + off; }
+    bool alloc(orbm* mm, size_t n) {
+        m = mm; bytes = n;
+        const size_t start = (m->arOff + 255) & ~(size_t)255, end = start + std::max<size_t>(n, 4);
+        if (end > m->arCap) {                               // grow: new blocks, staged bytes move over, old blocks go
+            const size_t ncap = std::max(end * 2, (size_t)1 << 20);
+            uint8_t *nd = nullptr, *np = nullptr;
+            if (hipMalloc((void**)&nd, ncap) != hipSuccess || hipHostMalloc((void**)&np, ncap, hipHostMallocDefault) != hipSuccess) {
+                if (nd) (void)hipFree(nd);
+                return false;
+            }
+            if (m->arPin && m->arOff) memcpy(np, m->arPin, m->arOff);
+            (void)hipStreamSynchronize(m->stream);
+            if (m->arDev) (void)hipFree(m->arDev);
+            if (m->arPin) (void)hipHostFree(m->arPin);
+            m->arDev = nd; m->arPin = np; m->arCap = ncap;
+        }
+        off = start; m->arOff = end; ok = true;
+        return true;
+    }
+    bool upload(orbm* mm, const void* src, size_t n) {
+        if (!alloc(mm, n)) return false;
+        if (n) memcpy(m->arPin + off, src, n);
+        m->arUp = m->arOff;
+        return true;
+    }
 };
-#define UP(buf, src, bytes) do { if (!(buf).upload((src), (bytes))) { set_merr("device upload failed (%zu B)", (size_t)(bytes)); return ORBM_E_HIP; } } while (0)
-#define AL(buf, bytes) do { if (!(buf).alloc((bytes))) { set_merr("device allocation failed (%zu B)", (size_t)(bytes)); return ORBM_E_HIP; } } while (0)
+static inline void arena_reset(orbm* m) { m->arOff = 0; m->arUp = 0; m->arOutLo = (size_t)-1; m->arOutHi = 0; }
+#define UP(buf, src, bytes) do { if (!(buf).upload(m, (src), (bytes))) { set_merr("device upload failed (%zu B)", (size_t)(bytes)); return ORBM_E_HIP; } } while (0)
+#define AL(buf, bytes) do { if (!(buf).alloc(m, (bytes))) { set_merr("device allocation failed (%zu B)", (size_t)(bytes)); return ORBM_E_HIP; } \
+                            m->arOutLo = std::min(m->arOutLo, (buf).off); m->arOutHi = std::max(m->arOutHi, m->arOff); } while (0)
+// large output read back selectively by the caller (not part of the ARENA_FETCH range): allocate these LAST
+#define AL_BIG(buf, bytes) do { if (!(buf).alloc(m, (bytes))) { set_merr("device allocation failed (%zu B)", (size_t)(bytes)); return ORBM_E_HIP; } } while (0)
+#define UPIO(buf, src, bytes) do { UP(buf, src, bytes); m->arOutLo = std::min(m->arOutLo, (buf).off); m->arOutHi = std::max(m->arOutHi, m->arOff); } while (0)   /* in/out buffer */
+// one host-to-device copy for everything staged so far / one device-to-host copy of everything behind the uploads
+#define ARENA_FLUSH(m) do { if ((m)->arUp) MHIPCHK(hipMemcpyAsync((m)->arDev, (m)->arPin, (m)->arUp, hipMemcpyHostToDevice, (m)->stream)); } while (0)
+#define ARENA_FETCH(m) do { if ((m)->arOutHi > (m)->arOutLo) MHIPCHK(hipMemcpy((m)->arPin + (m)->arOutLo, (m)->arDev + (m)->arOutLo, (m)->arOutHi - (m)->arOutLo, hipMemcpyDeviceToHost)); } while (0)
 
 struct RotHist {                                             // rotation-consistency histogram (e.g. ORBmatcher.cc:459-466)
     std::vector<int> bins[ORBM_HISTO_LENGTH];
@@ -193,11 +235,13 @@ struct RotHist {                                             // rotation-consist
 // runs k_window for nq windows against frame f; candidate lists come back in host vectors
 int window_pass(orbm* m, const orbm_frame_t* f, int nq, const float* qx, const float* qy, const float* qr,
                 const int32_t* minl, const int32_t* maxl, const float* qur, const float* qer, const uint8_t* qdesc,
-                int cap, std::vector<int>& cnt, std::vector<int>& idx, std::vector<int>& dist) {
+                int& cap, std::vector<int>& cnt, std::vector<int>& idx, std::vector<int>& dist) {
+    // `cap` in: capacity of a window on the device; out: row stride of idx / dist (= the longest candidate list, >= 1)
     cnt.assign(nq, 0);
     if (nq == 0 || f->n == 0) return ORBM_OK;
     MHIPCHK(hipSetDevice(m->device));
-    DevBuf dk, dd, du, dgs, dgi, dqx, dqy, dqr, dmin, dmax, dqu, dqe, dqd, dcnt, didx, ddist, dovf;
+    DevBuf dk, dd, du, dgs, dgi, dqx, dqy, dqr, dmin, dmax, dqu, dqe, dqd, dcnt, didx, ddist, dovf, dpack;
+    arena_reset(m);
     UP(dk, f->kps, sizeof(KpIn) * f->n); UP(dd, f->desc, (size_t)32 * f->n);
     if (f->uright) UP(du, f->uright, sizeof(float) * f->n);
     UP(dgs, f->grid_start, sizeof(int) * (ORBM_GRID_COLS * ORBM_GRID_ROWS + 1));
@@ -207,9 +251,12 @@ int window_pass(orbm* m, const orbm_frame_t* f, int nq, const float* qx, const f
     if (qur) UP(dqu, qur, sizeof(float) * nq);
     if (qer) UP(dqe, qer, sizeof(float) * nq);
     UP(dqd, qdesc, (size_t)32 * nq);
-    AL(dcnt, sizeof(int) * nq); AL(didx, sizeof(int) * (size_t)nq * cap); AL(ddist, sizeof(int) * (size_t)nq * cap); AL(dovf, sizeof(int));
-    MHIPCHK(hipMemsetAsync(dovf.p, 0, sizeof(int), m->stream));
+    AL(dcnt, sizeof(int) * nq); AL(dovf, sizeof(int));
+    AL_BIG(didx, sizeof(int) * (size_t)nq * cap); AL_BIG(ddist, sizeof(int) * (size_t)nq * cap);   // [nq][cap]: only the used columns come back
+    AL_BIG(dpack, 2 * sizeof(int) * (size_t)nq * cap);       // packed copy of the used columns (reserved now: the arena must not grow after the launch)
+    MHIPCHK(hipMemsetAsync(dovf.ptr(), 0, sizeof(int), m->stream));
     MHIPCHK(hipEventRecord(m->e0, m->stream));
+    ARENA_FLUSH(m);
     hipLaunchKernelGGL(k_window, dim3((nq + 3) / 4), dim3(256), 0, m->stream, dk.as<KpIn>(), dd.as<uint8_t>(),
                        f->uright ? du.as<float>() : nullptr, dgs.as<int>(), dgi.as<int>(), f->min_x, f->min_y, f->inv_w, f->inv_h,
                        nq, dqx.as<float>(), dqy.as<float>(), dqr.as<float>(), dmin.as<int>(), dmax.as<int>(),
@@ -219,13 +266,26 @@ int window_pass(orbm* m, const orbm_frame_t* f, int nq, const float* qx, const f
     m->timed = true;
     MHIPCHK(hipGetLastError());
     MHIPCHK(hipStreamSynchronize(m->stream));
+    ARENA_FETCH(m);
     int ovf = 0;
-    MHIPCHK(hipMemcpy(&ovf, dovf.p, sizeof(int), hipMemcpyDeviceToHost));
-    idx.resize((size_t)nq * cap); dist.resize((size_t)nq * cap);
-    MHIPCHK(hipMemcpy(cnt.data(), dcnt.p, sizeof(int) * nq, hipMemcpyDeviceToHost));
-    MHIPCHK(hipMemcpy(idx.data(), didx.p, sizeof(int) * (size_t)nq * cap, hipMemcpyDeviceToHost));
-    MHIPCHK(hipMemcpy(dist.data(), ddist.p, sizeof(int) * (size_t)nq * cap, hipMemcpyDeviceToHost));
-    if (ovf) { set_merr("a search window returned more than %d candidates", cap); return ORBM_E_CAPACITY; }
+    memcpy(&ovf, dovf.host(), sizeof(int));
+    memcpy(cnt.data(), dcnt.host(), sizeof(int) * nq);
+    const int devCap = cap;
+    int maxc = 0;
+    for (int i = 0; i < nq; ++i) maxc = std::max(maxc, std::min(cnt[i], devCap));
+    const size_t pn = (size_t)nq * std::max(maxc, 1);
+    idx.resize(pn); dist.resize(pn);
+    if (maxc > 0) {                                         // pack the used columns on the device: one contiguous copy, stride maxc
+        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((pn + 255) / 256)), dim3(256), 0, m->stream, didx.as<int>(), ddist.as<int>(), nq, devCap, maxc,
+                           dpack.as<int>(), dpack.as<int>() + pn);
+        MHIPCHK(hipGetLastError());
+        MHIPCHK(hipMemcpyAsync(m->arPin + dpack.off, m->arDev + dpack.off, 2 * sizeof(int) * pn, hipMemcpyDeviceToHost, m->stream));
+        MHIPCHK(hipStreamSynchronize(m->stream));
+        memcpy(idx.data(), dpack.host(), sizeof(int) * pn);
+        memcpy(dist.data(), (const int*)dpack.host() + pn, sizeof(int) * pn);
+    }
+    cap = std::max(maxc, 1);
+    if (ovf) { set_merr("a search window returned more than %d candidates", devCap); return ORBM_E_CAPACITY; }
     return ORBM_OK;
 }
 
@@ -238,18 +298,21 @@ int bucket_pass(orbm* m, const uint8_t* d1, int n1, const uint8_t* d2, int n2, c
     if (J.total == 0) return ORBM_OK;
     MHIPCHK(hipSetDevice(m->device));
     DevBuf b1, b2, bi, bq, bl, bo, bout;
+    arena_reset(m);
     UP(b1, d1, (size_t)32 * n1); UP(b2, d2, (size_t)32 * n2); UP(bi, idx2, sizeof(int) * nidx2);
     const int nj = (int)J.q.size();
     UP(bq, J.q.data(), sizeof(int) * nj); UP(bl, J.l2.data(), sizeof(int) * nj); UP(bo, J.off.data(), sizeof(int) * nj);
     AL(bout, sizeof(int) * (size_t)J.total);
     MHIPCHK(hipEventRecord(m->e0, m->stream));
+    ARENA_FLUSH(m);
     hipLaunchKernelGGL(k_pairdist, dim3((J.total + 255) / 256), dim3(256), 0, m->stream, b1.as<uint8_t>(), b2.as<uint8_t>(),
                        bi.as<int>(), nj, bq.as<int>(), bl.as<int>(), bo.as<int>(), J.total, bout.as<int>());
     MHIPCHK(hipEventRecord(m->e1, m->stream));
     m->timed = true;
     MHIPCHK(hipGetLastError());
     MHIPCHK(hipStreamSynchronize(m->stream));
-    MHIPCHK(hipMemcpy(dist.data(), bout.p, sizeof(int) * (size_t)J.total, hipMemcpyDeviceToHost));
+    ARENA_FETCH(m);
+    memcpy(dist.data(), bout.host(), sizeof(int) * (size_t)J.total);
     return ORBM_OK;
 }
 
@@ -265,17 +328,20 @@ int orbm_grid_build(orbm_t* m, const orbm_kp_t* kps, int n, float min_x, float m
     int n2 = 64; while (n2 < n) n2 <<= 1;
     if ((size_t)n2 * 4 > 150 * 1024) { set_merr("too many keypoints for the LDS sort"); return ORBM_E_CAPACITY; }
     DevBuf dk, dgs, dgi, dpl;
+    arena_reset(m);
     UP(dk, kps, sizeof(KpIn) * n);
     AL(dgs, sizeof(int) * (ORBM_GRID_COLS * ORBM_GRID_ROWS + 1)); AL(dgi, sizeof(int) * (n + 1)); AL(dpl, sizeof(int));
     MHIPCHK(hipFuncSetAttribute((const void*)k_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 4));
+    ARENA_FLUSH(m);
     hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), (size_t)n2 * 4, m->stream, dk.as<KpIn>(), n, n2, min_x, min_y, inv_w, inv_h,
                        dgs.as<int>(), dgi.as<int>(), dpl.as<int>());
     MHIPCHK(hipGetLastError());
     MHIPCHK(hipStreamSynchronize(m->stream));
+    ARENA_FETCH(m);
     int placed = 0;
-    MHIPCHK(hipMemcpy(&placed, dpl.p, sizeof(int), hipMemcpyDeviceToHost));
-    MHIPCHK(hipMemcpy(grid_start, dgs.p, sizeof(int) * (ORBM_GRID_COLS * ORBM_GRID_ROWS + 1), hipMemcpyDeviceToHost));
-    if (placed) MHIPCHK(hipMemcpy(grid_idx, dgi.p, sizeof(int) * placed, hipMemcpyDeviceToHost));
+    memcpy(&placed, dpl.host(), sizeof(int));
+    memcpy(grid_start, dgs.host(), sizeof(int) * (ORBM_GRID_COLS * ORBM_GRID_ROWS + 1));
+    if (placed) memcpy(grid_idx, dgi.host(), sizeof(int) * placed);
     return placed;
 }
 
@@ -284,10 +350,17 @@ int orbm_window_candidates(orbm_t* m, const orbm_frame_t* f, int nq, const float
                            const uint8_t* qdesc, int cap, int32_t* out_cnt, int32_t* out_idx, int32_t* out_dist) {
     if (!m || !f || nq < 0 || cap < 1) return ORBM_E_INVALID;
     std::vector<int> cnt, idx, dist;
-    int rc = window_pass(m, f, nq, qx, qy, qr, min_level, max_level, q_ur, q_er_max, qdesc, cap, cnt, idx, dist);
+    int stride = cap;                                        // in: window capacity; out: row stride of the packed lists
+    int rc = window_pass(m, f, nq, qx, qy, qr, min_level, max_level, q_ur, q_er_max, qdesc, stride, cnt, idx, dist);
     if (rc && rc != ORBM_E_CAPACITY) return rc;
-    for (int i = 0; i < nq; ++i) out_cnt[i] = cnt[i];
-    if (!idx.empty()) { memcpy(out_idx, idx.data(), idx.size() * sizeof(int)); memcpy(out_dist, dist.data(), dist.size() * sizeof(int)); }
+    for (int i = 0; i < nq; ++i) {
+        out_cnt[i] = cnt[i];
+        const int c = std::min(cnt[i], cap);
+        if (c > 0 && !idx.empty()) {
+            memcpy(out_idx + (size_t)i * cap, &idx[(size_t)i * stride], sizeof(int) * c);
+            memcpy(out_dist + (size_t)i * cap, &dist[(size_t)i * stride], sizeof(int) * c);
+        }
+    }
     return rc;
 }
 
@@ -310,7 +383,7 @@ int orbm_search_by_projection_frame(orbm_t* m, const orbm_frame_t* cur, const ui
         qur[i] = u[i] - mbf * invzc[i];                                    // :2571
         qer[i] = cur->uright ? radius : -1.f;
     }
-    const int cap = std::max(1, std::min(cur->n, 2048));
+    int cap = std::max(1, std::min(cur->n, 2048));      // becomes the row stride of idx / dist after window_pass
     std::vector<int> cnt, idx, dist;
     int rc = window_pass(m, cur, nq, u, v, qr.data(), minl.data(), maxl.data(), qur.data(), qer.data(), qdesc, cap, cnt, idx, dist);
     if (rc) return rc;
@@ -362,7 +435,7 @@ int orbm_search_by_projection_points(orbm_t* m, const orbm_frame_t* f, const uin
         minl[i] = level[i] - 1; maxl[i] = level[i];
         qer[i] = f->uright ? r * sf[level[i]] : -1.f;                      // :107-117
     }
-    const int cap = std::max(1, std::min(f->n, 2048));
+    int cap = std::max(1, std::min(f->n, 2048));      // becomes the row stride of idx / dist after window_pass
     std::vector<int> cnt, idx, dist;
     int rc = window_pass(m, f, nq, px, py, qr.data(), minl.data(), maxl.data(), pxr, qer.data(), qdesc, cap, cnt, idx, dist);
     if (rc) return rc;
@@ -403,7 +476,7 @@ int orbm_search_for_initialization(orbm_t* m, const orbm_frame_t* F1, const orbm
         if (l1 > 0) { qr[i] = -1.f; minl[i] = 0; maxl[i] = -1; }           // :825
         else { qr[i] = (float)windowSize; minl[i] = l1; maxl[i] = l1; }
     }
-    const int cap = std::max(1, std::min(F2->n, 4096));
+    int cap = std::max(1, std::min(F2->n, 4096));      // becomes the row stride of idx / dist after window_pass
     std::vector<int> cnt, idx, dist;
     int rc = window_pass(m, F2, n1, qx.data(), qy.data(), qr.data(), minl.data(), maxl.data(), nullptr, nullptr, F1->desc, cap, cnt, idx, dist);
     if (rc) return rc;
@@ -551,7 +624,7 @@ int orbm_search_by_projection_kf(orbm_t* m, const orbm_frame_t* cur, const uint8
         if (!valid[i]) { qr[i] = -1.f; minl[i] = 0; maxl[i] = -1; continue; }
         qr[i] = th * sf[level[i]]; minl[i] = level[i] - 1; maxl[i] = level[i] + 1;      // :2775-2778
     }
-    const int cap = std::max(1, std::min(cur->n, 2048));
+    int cap = std::max(1, std::min(cur->n, 2048));      // becomes the row stride of idx / dist after window_pass
     std::vector<int> cnt, idx, dist;
     orbm_frame_t f = *cur; f.uright = nullptr;                              // this overload has no stereo gate
     int rc = window_pass(m, &f, nq, u, v, qr.data(), minl.data(), maxl.data(), nullptr, nullptr, qdesc, cap, cnt, idx, dist);
@@ -596,7 +669,7 @@ int orbm_search_by_projection_sim3(orbm_t* m, const orbm_frame_t* kf, const uint
         if (!valid[i]) { qr[i] = -1.f; minl[i] = 0; maxl[i] = -1; continue; }
         qr[i] = th * sf[level[i]]; minl[i] = level[i] - 1; maxl[i] = level[i];          // :600-601, :625-627
     }
-    const int cap = std::max(1, std::min(kf->n, 2048));
+    int cap = std::max(1, std::min(kf->n, 2048));      // becomes the row stride of idx / dist after window_pass
     std::vector<int> cnt, idx, dist;
     orbm_frame_t f = *kf; f.uright = nullptr;
     int rc = window_pass(m, &f, nq, u, v, qr.data(), minl.data(), maxl.data(), nullptr, nullptr, qdesc, cap, cnt, idx, dist);
@@ -628,7 +701,7 @@ int orbm_fuse(orbm_t* m, const orbm_frame_t* kf, const float* sf, const float* i
         if (!valid[i]) { qr[i] = -1.f; minl[i] = 0; maxl[i] = -1; continue; }
         qr[i] = th * sf[level[i]]; minl[i] = level[i] - 1; maxl[i] = level[i];
     }
-    const int cap = std::max(1, std::min(kf->n, 2048));
+    int cap = std::max(1, std::min(kf->n, 2048));      // becomes the row stride of idx / dist after window_pass
     std::vector<int> cnt, idx, dist;
     orbm_frame_t f = *kf; f.uright = nullptr;                               // the chi2 gate below is not a window gate
     int rc = window_pass(m, &f, nq, u, v, qr.data(), minl.data(), maxl.data(), nullptr, nullptr, qdesc, cap, cnt, idx, dist);
@@ -670,7 +743,7 @@ static int sim3_one_way(orbm* m, const orbm_frame_t* src, const orbm_frame_t* ds
         if (!valid[i]) { qr[i] = -1.f; minl[i] = 0; maxl[i] = -1; continue; }
         qr[i] = th * sf_dst[level[i]]; minl[i] = level[i] - 1; maxl[i] = level[i];
     }
-    const int cap = std::max(1, std::min(dst->n, 2048));
+    int cap = std::max(1, std::min(dst->n, 2048));      // becomes the row stride of idx / dist after window_pass
     std::vector<int> cnt, idx, dist;
     orbm_frame_t f = *dst; f.uright = nullptr;
     int rc = window_pass(m, &f, nq, u, v, qr.data(), minl.data(), maxl.data(), nullptr, nullptr, qdesc, cap, cnt, idx, dist);
@@ -827,18 +900,21 @@ int orbm_bow_transform(orbm_t* m, const orbm_vocab_t* v, const uint8_t* desc, in
     if (v->device != m->device) { set_merr("vocabulary lives on another device"); return ORBM_E_INVALID; }
     MHIPCHK(hipSetDevice(m->device));
     DevBuf dd, dw, dn, dwt;
+    arena_reset(m);
     UP(dd, desc, (size_t)32 * n); AL(dw, sizeof(int) * n); AL(dn, sizeof(int) * n); AL(dwt, sizeof(double) * n);
     m->gridFirst = false;
     MHIPCHK(hipEventRecord(m->e0, m->stream));
+    ARENA_FLUSH(m);
     hipLaunchKernelGGL(k_bow_transform, dim3((n + 255) / 256), dim3(256), 0, m->stream, dd.as<uint8_t>(), n, v->dChildStart, v->dChildIdx,
                        v->dDesc, v->dWord, v->dWeight, v->L, levelsup, dw.as<int>(), dn.as<int>(), dwt.as<double>());
     MHIPCHK(hipEventRecord(m->e1, m->stream));
     m->timed = true;
     MHIPCHK(hipGetLastError());
     MHIPCHK(hipStreamSynchronize(m->stream));
-    MHIPCHK(hipMemcpy(word_id, dw.p, sizeof(int) * n, hipMemcpyDeviceToHost));
-    MHIPCHK(hipMemcpy(node_id, dn.p, sizeof(int) * n, hipMemcpyDeviceToHost));
-    MHIPCHK(hipMemcpy(weight, dwt.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    ARENA_FETCH(m);
+    memcpy(word_id, dw.host(), sizeof(int) * n);
+    memcpy(node_id, dn.host(), sizeof(int) * n);
+    memcpy(weight, dwt.host(), sizeof(double) * n);
     return ORBM_OK;
 }
 
@@ -891,7 +967,7 @@ int orbm_search_by_projection_frame_fisheye(orbm_t* m, const orbm_frame_t* cur_l
         if (bForward) { minl[i] = o; maxl[i] = -1; } else if (bBackward) { minl[i] = 0; maxl[i] = o; } else { minl[i] = o - 1; maxl[i] = o + 1; }
     }
     orbm_frame_t fl = *cur_l, fr = *cur_r; fl.uright = nullptr; fr.uright = nullptr;     // no stereo gate when Nleft != -1 (:2569)
-    const int capL = std::max(1, std::min(fl.n, 2048)), capR = std::max(1, std::min(fr.n, 2048));
+    int capL = std::max(1, std::min(fl.n, 2048)), capR = std::max(1, std::min(fr.n, 2048));      // row strides after window_pass
     std::vector<int> cntL, idxL, distL, cntR, idxR, distR;
     int rc = window_pass(m, &fl, nq, u, v, qr.data(), minl.data(), maxl.data(), nullptr, nullptr, qdesc, capL, cntL, idxL, distL);
     if (rc) return rc;
@@ -967,7 +1043,7 @@ int orbm_search_by_projection_points_fisheye(orbm_t* m, const orbm_frame_t* f_l,
         }
     }
     orbm_frame_t fl = *f_l, fr = *f_r; fl.uright = nullptr; fr.uright = nullptr;
-    const int capL = std::max(1, std::min(fl.n, 2048)), capR = std::max(1, std::min(fr.n, 2048));
+    int capL = std::max(1, std::min(fl.n, 2048)), capR = std::max(1, std::min(fr.n, 2048));      // row strides after window_pass
     std::vector<int> cntL, idxL, distL, cntR, idxR, distR;
     int rc = window_pass(m, &fl, nq, px, py, qrl.data(), minL.data(), maxL.data(), nullptr, nullptr, qdesc, capL, cntL, idxL, distL);
     if (rc) return rc;
@@ -1177,19 +1253,22 @@ int orbm_stereo_matches(orbm_t* m, void* left, int frame_l, void* right, int fra
     if (nlev != nlevR || devL != m->device || devR != m->device) { set_merr("extractors and matcher must share one device and level count"); return ORBM_E_INVALID; }
     MHIPCHK(hipSetDevice(m->device));
     DevBuf bkl, bdl, bkr, bdr, bur, bde, bsad;
+    arena_reset(m);
     UP(bkl, kl, sizeof(KpIn) * nl); UP(bdl, dl, (size_t)32 * nl); UP(bkr, kr, sizeof(KpIn) * nr); UP(bdr, dr, (size_t)32 * nr);
     AL(bur, sizeof(float) * nl); AL(bde, sizeof(float) * nl); AL(bsad, sizeof(int) * nl);
     MHIPCHK(hipEventRecord(m->e0, m->stream));
+    ARENA_FLUSH(m);
     hipLaunchKernelGGL(k_stereo, dim3((nl + 3) / 4), dim3(256), 0, m->stream, bkl.as<KpIn>(), bdl.as<uint8_t>(), nl, bkr.as<KpIn>(),
                        bdr.as<uint8_t>(), nr, lv, mb, mbf, bur.as<float>(), bde.as<float>(), bsad.as<int>());
     MHIPCHK(hipEventRecord(m->e1, m->stream));
     m->timed = true;
     MHIPCHK(hipGetLastError());
     MHIPCHK(hipStreamSynchronize(m->stream));
+    ARENA_FETCH(m);
     std::vector<int> sad(nl);
-    MHIPCHK(hipMemcpy(uright, bur.p, sizeof(float) * nl, hipMemcpyDeviceToHost));
-    MHIPCHK(hipMemcpy(depth, bde.p, sizeof(float) * nl, hipMemcpyDeviceToHost));
-    MHIPCHK(hipMemcpy(sad.data(), bsad.p, sizeof(int) * nl, hipMemcpyDeviceToHost));
+    memcpy(uright, bur.host(), sizeof(float) * nl);
+    memcpy(depth, bde.host(), sizeof(float) * nl);
+    memcpy(sad.data(), bsad.host(), sizeof(int) * nl);
     // median cut (Frame.cc:1261-1275)
     std::vector<std::pair<int, int>> vDistIdx;
     for (int i = 0; i < nl; ++i) if (sad[i] >= 0) vDistIdx.push_back(std::make_pair(sad[i], i));
@@ -1227,11 +1306,14 @@ int orbm_undistort_keypoints(orbm_t* m, int space, const orbm_kp_t* kps, int n, 
         return n;
     }
     DevBuf di, dout;
+    arena_reset(m);
     UP(di, kps, sizeof(KpIn) * n); AL(dout, sizeof(KpIn) * n);
+    ARENA_FLUSH(m);
     hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, m->stream, di.as<KpIn>(), n, P, pass, dout.as<KpIn>());
     MHIPCHK(hipGetLastError());
     MHIPCHK(hipStreamSynchronize(m->stream));
-    MHIPCHK(hipMemcpy(out, dout.p, sizeof(KpIn) * n, hipMemcpyDeviceToHost));
+    ARENA_FETCH(m);
+    memcpy(out, dout.host(), sizeof(KpIn) * n);
     return n;
 }
 
@@ -1268,21 +1350,22 @@ int orbm_is_in_frustum(orbm_t* m, int space, int n, const float* pw, const float
         return 0;
     }
     DevBuf dp, dn, dmin, dmax, div, dx, dy, dxr, dd, dl, dvc;
+    arena_reset(m);
     UP(dp, pw, sizeof(float) * 3 * n); UP(dn, normal, sizeof(float) * 3 * n); UP(dmin, min_dist, sizeof(float) * n); UP(dmax, max_dist, sizeof(float) * n);
-    AL(div, n); AL(dx, sizeof(float) * n); AL(dy, sizeof(float) * n); AL(dxr, sizeof(float) * n); AL(dd, sizeof(float) * n);
-    AL(dl, sizeof(int) * n); AL(dvc, sizeof(float) * n);
+    AL(div, n); AL(dx, sizeof(float) * n); AL(dy, sizeof(float) * n);
     // the reference leaves mTrackProjXR / mTrackDepth / mnTrackScaleLevel / mTrackViewCos untouched for rejected points:
-    // start from the caller's values
-    MHIPCHK(hipMemcpy(dxr.p, proj_xr, sizeof(float) * n, hipMemcpyHostToDevice)); MHIPCHK(hipMemcpy(dd.p, depth, sizeof(float) * n, hipMemcpyHostToDevice));
-    MHIPCHK(hipMemcpy(dl.p, level, sizeof(int) * n, hipMemcpyHostToDevice)); MHIPCHK(hipMemcpy(dvc.p, view_cos, sizeof(float) * n, hipMemcpyHostToDevice));
+    // in/out buffers that start from the caller's values
+    UPIO(dxr, proj_xr, sizeof(float) * n); UPIO(dd, depth, sizeof(float) * n); UPIO(dl, level, sizeof(int) * n); UPIO(dvc, view_cos, sizeof(float) * n);
+    ARENA_FLUSH(m);
     hipLaunchKernelGGL(k_frustum, grid, block, 0, m->stream, n, dp.as<float>(), dn.as<float>(), dmin.as<float>(), dmax.as<float>(), F,
                        div.as<uint8_t>(), dx.as<float>(), dy.as<float>(), dxr.as<float>(), dd.as<float>(), dl.as<int>(), dvc.as<float>());
     MHIPCHK(hipGetLastError());
     MHIPCHK(hipStreamSynchronize(m->stream));
-    MHIPCHK(hipMemcpy(in_view, div.p, n, hipMemcpyDeviceToHost)); MHIPCHK(hipMemcpy(proj_x, dx.p, sizeof(float) * n, hipMemcpyDeviceToHost));
-    MHIPCHK(hipMemcpy(proj_y, dy.p, sizeof(float) * n, hipMemcpyDeviceToHost)); MHIPCHK(hipMemcpy(proj_xr, dxr.p, sizeof(float) * n, hipMemcpyDeviceToHost));
-    MHIPCHK(hipMemcpy(depth, dd.p, sizeof(float) * n, hipMemcpyDeviceToHost)); MHIPCHK(hipMemcpy(level, dl.p, sizeof(int) * n, hipMemcpyDeviceToHost));
-    MHIPCHK(hipMemcpy(view_cos, dvc.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    ARENA_FETCH(m);
+    memcpy(in_view, div.host(), n); memcpy(proj_x, dx.host(), sizeof(float) * n);
+    memcpy(proj_y, dy.host(), sizeof(float) * n); memcpy(proj_xr, dxr.host(), sizeof(float) * n);
+    memcpy(depth, dd.host(), sizeof(float) * n); memcpy(level, dl.host(), sizeof(int) * n);
+    memcpy(view_cos, dvc.host(), sizeof(float) * n);
     int cnt = 0;
     for (int i = 0; i < n; ++i) cnt += in_view[i] ? 1 : 0;
     return cnt;

@@ -602,4 +602,15 @@ __global__ __launch_bounds__(256) void k_frustum(int n, const float* __restrict_
     inView[i] = 1; projXR[i] = u - F.bf * invz; depth[i] = PcDist; level[i] = ns; viewCos[i] = vc;
 }
 
+// k_gather_rows: packs the used prefix of every row of the two [nq][cap] candidate arrays into [nq][maxc] (one contiguous
+// device-to-host copy instead of nq*cap entries or a strided copy).
+__global__ __launch_bounds__(256) void k_gather_rows(const int* __restrict__ idx, const int* __restrict__ dist, int nq, int cap, int maxc,
+                                                     int* __restrict__ oidx, int* __restrict__ odist) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq * maxc) return;
+    const int q = i / maxc, k = i - q * maxc;
+    oidx[i] = idx[(size_t)q * cap + k];
+    odist[i] = dist[(size_t)q * cap + k];
+}
+
 }  // namespace orbmk
