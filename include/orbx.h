@@ -107,8 +107,9 @@ int orbx_stream_wait_other(orbx_t*, void* other_stream);
  * (src/Tracking.cc:1264-1290, 1339-1348, 1393-1402).  nimg interleaved 8-bit colour images (src_space = ORBX_HOST | ORBX_DEVICE)
  * are converted into the caller's DEVICE buffers dst[i] (dst_stride bytes per row; a multiple of 16 lets orbx_extract_batch*
  * use them in place).  gray = (R*RY + G*GY + B*BY + half) >> coef_bits; coef_bits = 14: OpenCV 3.x coefficients
- * (4899, 9617, 1868), 15: OpenCV 4.x (9798, 19235, 3735).  Enqueued on the extractor's stream (ordered before the next
- * orbx_extract_batch_async). */
+ * (4899, 9617, 1868), 15: OpenCV 4.x (9798, 19235, 3735).  The three ingest entry points only ENQUEUE on the extractor's
+ * stream (ordered before the next orbx_extract_batch_async; no allocation, no host sync): call orbx_sync before reading
+ * their output from the host, and keep device inputs alive until then. */
 int orbx_gray_from_color(orbx_t*, const uint8_t* const* src, int src_space, int nimg, int w, int h, int src_stride,
                          int channels, int blue_first, int coef_bits, uint8_t* const* dst, int dst_stride);
 /* SURVEY 8(f).4 stereo rectification -- replaces cv::remap(im, imRect, M1, M2, cv::INTER_LINEAR) of the stereo examples

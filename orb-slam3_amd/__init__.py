@@ -246,6 +246,7 @@ class ORBextractor:
         dsts = (C.c_void_p * len(imgs))(*[buf.ptr + k * stride * h for k in range(len(imgs))])
         _chk(self.L.orbx_gray_from_color(self.h, srcs, HOST, len(imgs), w, h, w * ch, ch, 1 if blue_first else 0, int(coef_bits), dsts, stride),
              "orbx_gray_from_color")
+        self.sync()                                        # enqueue-only in the C ABI; synced here because callers download the buffer
         return buf, stride
 
     def clahe(self, images, clip_limit=3.0, tiles=(8, 8)):
@@ -261,6 +262,7 @@ class ORBextractor:
             buf.upload(pad, offset=k * stride * h)
         ptrs = (C.c_void_p * len(imgs))(*[buf.ptr + k * stride * h for k in range(len(imgs))])
         _chk(self.L.orbx_clahe(self.h, ptrs, len(imgs), w, h, stride, float(clip_limit), int(tiles[0]), int(tiles[1]), ptrs, stride), "orbx_clahe")
+        self.sync()
         return buf, stride
 
     def remap_linear(self, images, mapx, mapy):
@@ -280,6 +282,7 @@ class ORBextractor:
         sp = (C.c_void_p * len(imgs))(*[src.ptr + k * sstride * sh for k in range(len(imgs))])
         dp = (C.c_void_p * len(imgs))(*[dst.ptr + k * dstride * dh for k in range(len(imgs))])
         _chk(self.L.orbx_remap_linear(self.h, sp, len(imgs), sw, sh, sstride, dmx.ptr, dmy.ptr, dw, dh, dp, dstride), "orbx_remap_linear")
+        self.sync()                                        # the source / map buffers above are released when this returns
         return dst, dstride
 
     def enqueue_device(self, dev_ptrs, w, h, stride, lapping=None):

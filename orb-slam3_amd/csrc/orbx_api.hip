@@ -83,6 +83,7 @@ struct orbx {
     bool stageTiming = true;                                   // record the stage-boundary events (orbx_set_stage_timing)
     std::vector<int> hN, hMono; bool countsValid = false;      // per-frame counts of the last batch, fetched once
     u8* hPinned = nullptr; size_t capPinned = 0; hipEvent_t evH2D = nullptr;   // pinned staging of host images
+    u8* dIngest = nullptr; size_t capIngest = 0;               // grow-only scratch of the ingest entry points (pointer tables, staged colour images, CLAHE LUTs)
     std::vector<const u8*> upPtr; std::vector<int> upLap;      // what dL0Ptr / dLap currently hold
     u32 *dOvf = nullptr, *dOvfList = nullptr;                  // k_fast3 queue overflow list -> k_fast_fix
     size_t capOvfList = 0;
@@ -493,6 +494,7 @@ void orbx_destroy(orbx_t* o) {
     if (o->evDone) (void)hipEventDestroy(o->evDone);
     if (o->evH2D) (void)hipEventDestroy(o->evH2D);
     if (o->hPinned) (void)hipHostFree(o->hPinned);
+    if (o->dIngest) (void)hipFree(o->dIngest);
     for (auto& e : o->evLvl) if (e) (void)hipEventDestroy(e);
     if (o->stream) (void)hipStreamDestroy(o->stream);
     if (o->stream2) (void)hipStreamDestroy(o->stream2);
@@ -889,6 +891,18 @@ int orbx_stream_wait_other(orbx_t* o, void* other_stream) {
     return ORBX_OK;
 }
 
+// Scratch of the ingest entry points: grow-only, so a call needs no allocation, no free and no host sync (the kernels and the
+// small table uploads are ordered by the extractor's stream; a later call reuses the block only behind them in that stream).
+static u8* ingest_scratch(orbx* o, size_t bytes) {
+    if (bytes <= o->capIngest && o->dIngest) return o->dIngest;
+    (void)hipStreamSynchronize(o->stream);
+    if (o->dIngest) (void)hipFree(o->dIngest);
+    o->dIngest = nullptr; o->capIngest = 0;
+    if (hipMalloc((void**)&o->dIngest, bytes) != hipSuccess) { set_err("hipMalloc of %zu B failed", bytes); return nullptr; }
+    o->capIngest = bytes;
+    return o->dIngest;
+}
+
 int orbx_gray_from_color(orbx_t* o, const uint8_t* const* src, int src_space, int nimg, int w, int h, int src_stride,
                          int channels, int blue_first, int coef_bits, uint8_t* const* dst, int dst_stride) {
     if (!o || !src || !dst || nimg < 1 || w < 1 || h < 1 || (channels != 3 && channels != 4) || (coef_bits != 14 && coef_bits != 15) ||
@@ -898,34 +912,22 @@ int orbx_gray_from_color(orbx_t* o, const uint8_t* const* src, int src_space, in
     const int ry = coef_bits == 14 ? 4899 : 9798, gy = coef_bits == 14 ? 9617 : 19235, by = coef_bits == 14 ? 1868 : 3735;
     const int c0 = blue_first ? by : ry, c2 = blue_first ? ry : by;
     hipStream_t st = o->stream;
-    // pointer tables (and, for host sources, the staged colour images) live in scratch freed after the stream has consumed them
-    const size_t imgBytes = (size_t)src_stride * h;
-    u8* stage = nullptr; const u8** dS = nullptr; u8** dD = nullptr;
+    const size_t imgBytes = (size_t)src_stride * h, tab = (sizeof(u8*) * nimg + 255) & ~(size_t)255;
+    u8* sc = ingest_scratch(o, 2 * tab + (src_space != ORBX_DEVICE ? imgBytes * nimg : 0));
+    if (!sc) return ORBX_E_HIP;
+    const u8** dS = (const u8**)sc; u8** dD = (u8**)(sc + tab); u8* stage = sc + 2 * tab;
     std::vector<const u8*> hs(nimg);
-    int rc = ORBX_OK;
-    do {
-        if (hipMalloc((void**)&dS, sizeof(u8*) * nimg) != hipSuccess || hipMalloc((void**)&dD, sizeof(u8*) * nimg) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
+    for (int i = 0; i < nimg; ++i) {
         if (src_space != ORBX_DEVICE) {
-            if (hipMalloc((void**)&stage, imgBytes * nimg) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
-            for (int i = 0; i < nimg && rc == ORBX_OK; ++i) {
-                if (hipMemcpyAsync(stage + imgBytes * i, src[i], imgBytes, hipMemcpyHostToDevice, st) != hipSuccess) { rc = ORBX_E_HIP; set_err("H2D failed"); }
-                hs[i] = stage + imgBytes * i;
-            }
-            if (rc) break;
-        } else {
-            for (int i = 0; i < nimg; ++i) hs[i] = src[i];
-        }
-        if (hipMemcpyAsync((void*)dS, hs.data(), sizeof(u8*) * nimg, hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync((void*)dD, dst, sizeof(u8*) * nimg, hipMemcpyHostToDevice, st) != hipSuccess) { rc = ORBX_E_HIP; set_err("H2D failed"); break; }
-        hipLaunchKernelGGL(k_gray, dim3((w + 1023) / 1024, h, nimg), dim3(256), 0, st, dS, w, h, src_stride, channels, c0, gy, c2, coef_bits,
-                           dD, dst_stride);
-        if (hipGetLastError() != hipSuccess) { rc = ORBX_E_HIP; set_err("k_gray launch failed"); break; }
-    } while (0);
-    (void)hipStreamSynchronize(st);                              // scratch is freed below; the conversion itself is a one-pass stream kernel
-    if (stage) (void)hipFree(stage);
-    if (dS) (void)hipFree((void*)dS);
-    if (dD) (void)hipFree((void*)dD);
-    return rc;
+            HIPCHK(hipMemcpyAsync(stage + imgBytes * i, src[i], imgBytes, hipMemcpyHostToDevice, st));
+            hs[i] = stage + imgBytes * i;
+        } else hs[i] = src[i];
+    }
+    HIPCHK(hipMemcpyAsync((void*)dS, hs.data(), sizeof(u8*) * nimg, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync((void*)dD, dst, sizeof(u8*) * nimg, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_gray, dim3((w + 1023) / 1024, h, nimg), dim3(256), 0, st, dS, w, h, src_stride, channels, c0, gy, c2, coef_bits, dD, dst_stride);
+    HIPCHK(hipGetLastError());
+    return ORBX_OK;
 }
 
 int orbx_remap_linear(orbx_t* o, const uint8_t* const* src, int nimg, int sw, int sh, int src_stride, const float* mapx, const float* mapy,
@@ -934,19 +936,15 @@ int orbx_remap_linear(orbx_t* o, const uint8_t* const* src, int nimg, int sw, in
     for (int i = 0; i < nimg; ++i) if (!src[i] || !dst[i]) return ORBX_E_EMPTY;
     HIPCHK(hipSetDevice(o->device));
     hipStream_t st = o->stream;
-    const u8** dS = nullptr; u8** dD = nullptr;
-    int rc = ORBX_OK;
-    do {
-        if (hipMalloc((void**)&dS, sizeof(u8*) * nimg) != hipSuccess || hipMalloc((void**)&dD, sizeof(u8*) * nimg) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
-        if (hipMemcpyAsync((void*)dS, src, sizeof(u8*) * nimg, hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync((void*)dD, dst, sizeof(u8*) * nimg, hipMemcpyHostToDevice, st) != hipSuccess) { rc = ORBX_E_HIP; set_err("H2D failed"); break; }
-        hipLaunchKernelGGL(k_remap, dim3((dw + 1023) / 1024, dh, nimg), dim3(256), 0, st, dS, sw, sh, src_stride, mapx, mapy, dw, dh, dD, dst_stride);
-        if (hipGetLastError() != hipSuccess) { rc = ORBX_E_HIP; set_err("k_remap launch failed"); break; }
-    } while (0);
-    (void)hipStreamSynchronize(st);                              // the pointer tables are freed below
-    if (dS) (void)hipFree((void*)dS);
-    if (dD) (void)hipFree((void*)dD);
-    return rc;
+    const size_t tab = (sizeof(u8*) * nimg + 255) & ~(size_t)255;
+    u8* sc = ingest_scratch(o, 2 * tab);
+    if (!sc) return ORBX_E_HIP;
+    const u8** dS = (const u8**)sc; u8** dD = (u8**)(sc + tab);
+    HIPCHK(hipMemcpyAsync((void*)dS, src, sizeof(u8*) * nimg, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync((void*)dD, dst, sizeof(u8*) * nimg, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_remap, dim3((dw + 1023) / 1024, dh, nimg), dim3(256), 0, st, dS, sw, sh, src_stride, mapx, mapy, dw, dh, dD, dst_stride);
+    HIPCHK(hipGetLastError());
+    return ORBX_OK;
 }
 
 int orbx_clahe(orbx_t* o, const uint8_t* const* src, int nimg, int w, int h, int src_stride, double clip_limit, int tiles_x, int tiles_y,
@@ -965,22 +963,16 @@ int orbx_clahe(orbx_t* o, const uint8_t* const* src, int nimg, int w, int h, int
     G.lutScale = (float)255 / area; G.invTw = 1.0f / G.tw; G.invTh = 1.0f / G.th;
     HIPCHK(hipSetDevice(o->device));
     hipStream_t st = o->stream;
-    const u8** dS = nullptr; u8** dD = nullptr; u8* dLut = nullptr;
-    int rc = ORBX_OK;
-    do {
-        if (hipMalloc((void**)&dS, sizeof(u8*) * nimg) != hipSuccess || hipMalloc((void**)&dD, sizeof(u8*) * nimg) != hipSuccess ||
-            hipMalloc((void**)&dLut, (size_t)nimg * tiles_x * tiles_y * 256) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
-        if (hipMemcpyAsync((void*)dS, src, sizeof(u8*) * nimg, hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync((void*)dD, dst, sizeof(u8*) * nimg, hipMemcpyHostToDevice, st) != hipSuccess) { rc = ORBX_E_HIP; set_err("H2D failed"); break; }
-        hipLaunchKernelGGL(k_clahe_lut, dim3(tiles_x * tiles_y, nimg), dim3(256), 0, st, dS, src_stride, G, dLut);
-        hipLaunchKernelGGL(k_clahe_apply, dim3((w + 1023) / 1024, h, nimg), dim3(256), 0, st, dS, src_stride, G, dLut, dD, dst_stride);
-        if (hipGetLastError() != hipSuccess) { rc = ORBX_E_HIP; set_err("CLAHE launch failed"); break; }
-    } while (0);
-    (void)hipStreamSynchronize(st);                              // scratch (pointer tables, LUTs) is freed below
-    if (dS) (void)hipFree((void*)dS);
-    if (dD) (void)hipFree((void*)dD);
-    if (dLut) (void)hipFree(dLut);
-    return rc;
+    const size_t tab = (sizeof(u8*) * nimg + 255) & ~(size_t)255;
+    u8* sc = ingest_scratch(o, 2 * tab + (size_t)nimg * tiles_x * tiles_y * 256);
+    if (!sc) return ORBX_E_HIP;
+    const u8** dS = (const u8**)sc; u8** dD = (u8**)(sc + tab); u8* dLut = sc + 2 * tab;
+    HIPCHK(hipMemcpyAsync((void*)dS, src, sizeof(u8*) * nimg, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync((void*)dD, dst, sizeof(u8*) * nimg, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles_x * tiles_y, nimg), dim3(256), 0, st, dS, src_stride, G, dLut);
+    hipLaunchKernelGGL(k_clahe_apply, dim3((w + 1023) / 1024, h, nimg), dim3(256), 0, st, dS, src_stride, G, dLut, dD, dst_stride);
+    HIPCHK(hipGetLastError());
+    return ORBX_OK;
 }
 
 int64_t orbx_algorithmic_bytes(const orbx_t* o, int64_t* fused_lower_bound) {
