@@ -36,6 +36,9 @@ struct orbm {
     size_t arCap = 0, arOff = 0, arUp = 0, arOutLo = (size_t)-1, arOutHi = 0;   // bump offset; [0, arUp) staged uploads; small outputs in [arOutLo, arOutHi)
 };
 
+namespace { int knn2_host(orbm* m, const uint8_t* q, int q_stride, const int32_t* nq, const uint8_t* t, int t_stride, const int32_t* nt,
+                          int npairs, int32_t* idx2, int32_t* dist2); }
+
 extern "C" {
 
 const char* orbm_last_error(void) { return g_merr.c_str(); }
@@ -130,27 +133,7 @@ int orbm_knn2_batch(orbm_t* m, int space, const uint8_t* q, int q_stride, const 
         return orbm_sync(m);
     }
     if (!q || !t || !nq || !nt || !idx2 || !dist2 || npairs < 1 || q_stride < 1 || t_stride < 1) return ORBM_E_INVALID;
-    MHIPCHK(hipSetDevice(m->device));
-    const size_t qb = (size_t)npairs * q_stride * 32, tb = (size_t)npairs * t_stride * 32, ob = (size_t)npairs * q_stride * 2 * sizeof(int);
-    uint8_t *dq = nullptr, *dt = nullptr; int *dnq = nullptr, *dnt = nullptr, *di = nullptr, *dd = nullptr;
-    int rc = ORBM_OK;
-    do {
-        if (hipMalloc((void**)&dq, qb) != hipSuccess || hipMalloc((void**)&dt, tb) != hipSuccess || hipMalloc((void**)&dnq, sizeof(int) * npairs) != hipSuccess ||
-            hipMalloc((void**)&dnt, sizeof(int) * npairs) != hipSuccess || hipMalloc((void**)&di, ob) != hipSuccess || hipMalloc((void**)&dd, ob) != hipSuccess) {
-            set_merr("hipMalloc failed"); rc = ORBM_E_HIP; break;
-        }
-        if (hipMemcpy(dq, q, qb, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dt, t, tb, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(dnq, nq, sizeof(int) * npairs, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(dnt, nt, sizeof(int) * npairs, hipMemcpyHostToDevice) != hipSuccess) { set_merr("H2D failed"); rc = ORBM_E_HIP; break; }
-        rc = orbm_knn2_batch_async(m, dq, q_stride, dnq, dt, t_stride, dnt, npairs, t_stride, di, dd);
-        if (rc) break;
-        rc = orbm_sync(m);
-        if (rc) break;
-        if (hipMemcpy(idx2, di, ob, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(dist2, dd, ob, hipMemcpyDeviceToHost) != hipSuccess) { set_merr("D2H failed"); rc = ORBM_E_HIP; }
-    } while (0);
-    void* ps[] = {dq, dt, dnq, dnt, di, dd};
-    for (void* p : ps) if (p) (void)hipFree(p);
-    return rc;
+    return knn2_host(m, q, q_stride, nq, t, t_stride, nt, npairs, idx2, dist2);
 }
 
 int orbm_last_timing(orbm_t* m, float* ms) {
@@ -215,6 +198,25 @@ static inline void arena_reset(orbm* m) { m->arOff = 0; m->arUp = 0; m->arOutLo 
 // one host-to-device copy for everything staged so far / one device-to-host copy of everything behind the uploads
 #define ARENA_FLUSH(m) do { if ((m)->arUp) MHIPCHK(hipMemcpyAsync((m)->arDev, (m)->arPin, (m)->arUp, hipMemcpyHostToDevice, (m)->stream)); } while (0)
 #define ARENA_FETCH(m) do { if ((m)->arOutHi > (m)->arOutLo) MHIPCHK(hipMemcpy((m)->arPin + (m)->arOutLo, (m)->arDev + (m)->arOutLo, (m)->arOutHi - (m)->arOutLo, hipMemcpyDeviceToHost)); } while (0)
+
+// host-array form of orbm_knn2_batch (Frame::ComputeStereoFishEyeMatches hands over host descriptors): through the arena
+int knn2_host(orbm* m, const uint8_t* q, int q_stride, const int32_t* nq, const uint8_t* t, int t_stride, const int32_t* nt,
+              int npairs, int32_t* idx2, int32_t* dist2) {
+    MHIPCHK(hipSetDevice(m->device));
+    const size_t qb = (size_t)npairs * q_stride * 32, tb = (size_t)npairs * t_stride * 32, ob = (size_t)npairs * q_stride * 2 * sizeof(int);
+    DevBuf dq, dt, dnq, dnt, di, dd;
+    arena_reset(m);
+    UP(dq, q, qb); UP(dt, t, tb); UP(dnq, nq, sizeof(int) * npairs); UP(dnt, nt, sizeof(int) * npairs);
+    AL(di, ob); AL(dd, ob);
+    ARENA_FLUSH(m);
+    int rc = orbm_knn2_batch_async(m, dq.as<uint8_t>(), q_stride, dnq.as<int32_t>(), dt.as<uint8_t>(), t_stride, dnt.as<int32_t>(), npairs, t_stride,
+                                   di.as<int32_t>(), dd.as<int32_t>());
+    if (rc) return rc;
+    MHIPCHK(hipStreamSynchronize(m->stream));
+    ARENA_FETCH(m);
+    memcpy(idx2, di.host(), ob); memcpy(dist2, dd.host(), ob);
+    return ORBM_OK;
+}
 
 struct RotHist {                                             // rotation-consistency histogram (e.g. ORBmatcher.cc:459-466)
     std::vector<int> bins[ORBM_HISTO_LENGTH];
