@@ -192,6 +192,24 @@ int orbm_search_for_triangulation_legacy(orbm_t*, int n1, const orbm_kp_t* kps1,
                                   const float* F12, float epx, float epy, const float* scale_factors2, const float* level_sigma2_2,
                                   int only_stereo, int coarse, int check_ori, int32_t* matches12);
 
+/* M10 with a second camera (pKF1->mpCamera2, ORBmatcher.cc:1413-1426, 1526-1557) and M12
+ * (ORBmatcher::SearchForTriangulation(+vMatchedPoints), ORBmatcher.cc:1632-1821).  Both are the M10 bucket search with the
+ * geometric gate supplied by the camera model (GeometricCamera::epipolarConstrain_ :1552, ::matchAndtriangulate :1729 —
+ * KannalaBrandt8 unprojects, triangulates with cv::SVD and tests the reprojection, KannalaBrandt8.cpp:356-361, 363-472,
+ * 559-700; Pinhole::matchAndtriangulate is `return false`, Pinhole.h:88-91), no epipole
+ * gate (:1517 needs !mpCamera2; M12 has none) and no stereo flags (bStereo is false with mpCamera2, :1462; M12 ignores
+ * bOnlyStereo).  The gate stays with the caller: `gate(user, idx1, idx2)` is called exactly where the reference calls the
+ * camera model — after the MapPoint and `dist <= TH_LOW && dist <= bestDist` tests, in bucket order — and a nonzero
+ * return accepts the pair, so a callback that records its last accepted x3D per idx1 reproduces M12's vMatchedPoints.
+ * kps1/kps2 are the N-long keypoint arrays the reference indexes (mvKeysUn, or mvKeys followed by mvKeysRight when
+ * NLeft != -1, :1467-1469); histogram factor 1/30 (:1441, :1672).  Descriptor distances are computed on the GPU. */
+typedef int (*orbm_pair_gate_fn)(void* user, int idx1, int idx2);
+int orbm_search_for_triangulation_gated(orbm_t*, int n1, const orbm_kp_t* kps1, const uint8_t* desc1, const uint8_t* has_mp1,
+                                        int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
+                                        int n2, const orbm_kp_t* kps2, const uint8_t* desc2, const uint8_t* has_mp2,
+                                        int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2,
+                                        orbm_pair_gate_fn gate, void* user, int check_ori, int32_t* matches12);
+
 /* ---- batched, DEVICE-resident forms: frame-to-frame tracking chained behind orbx_extract_batch_async with no host round
  * trip (kps/desc/counts are the extractor's result block, orbx_result_device; all pointers are device pointers).
  * orbm_grid_build_batch_async: M14 for every frame of the block; grid_start [nframes][3073], grid_idx [nframes][cap].

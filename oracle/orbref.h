@@ -111,6 +111,15 @@ int orbref_search_for_triangulation(int n1, const orbref_kp_t* kps1, const uint8
                                     int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2,
                                     const float* F12, float epx, float epy, const float* scale_factors2, const float* level_sigma2_2,
                                     int only_stereo, int coarse, int check_ori, int32_t* matches12);
+/* SearchForTriangulation_ with pKF1->mpCamera2 (ORBmatcher.cc:1413-1426, 1526-1557) and SearchForTriangulation(+vMatchedPoints)
+ * (ORBmatcher.cc:1632-1821): the bucket search with the camera model's gate (epipolarConstrain_ :1552 / matchAndtriangulate
+ * :1729) as a callback, called lazily at the reference's call site; no epipole gate, no stereo flags; factor 1/30. */
+typedef int (*orbref_pair_gate_fn)(void* user, int idx1, int idx2);
+int orbref_search_for_triangulation_gated(int n1, const orbref_kp_t* kps1, const uint8_t* desc1, const uint8_t* has_mp1,
+                                          int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
+                                          int n2, const orbref_kp_t* kps2, const uint8_t* desc2, const uint8_t* has_mp2,
+                                          int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2,
+                                          orbref_pair_gate_fn gate, void* user, int check_ori, int32_t* matches12);
 /* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (ORBmatcher.cc:314-547), Nleft == -1 path.
  * kf_good[i] = KF feature i has a MapPoint that is not bad.  Output f_match[iF] = KF feature index or -1. */
 int orbref_search_by_bow(int nkf, const orbref_kp_t* kps_kf, const uint8_t* desc_kf, const uint8_t* kf_good,

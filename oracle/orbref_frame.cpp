@@ -296,6 +296,55 @@ int orbref_search_for_triangulation(int n1, const orbref_kp_t* kps1, const uint8
     return nmatches;
 }
 
+int orbref_search_for_triangulation_gated(int n1, const orbref_kp_t* kps1, const uint8_t* desc1, const uint8_t* has_mp1,
+                                          int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1v,
+                                          int n2, const orbref_kp_t* kps2, const uint8_t* desc2, const uint8_t* has_mp2,
+                                          int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2v,
+                                          orbref_pair_gate_fn gate, void* user, int check_ori, int32_t* vMatches12) {
+    // ORBmatcher.cc:1632-1821 (and :1388-1629 with mpCamera2): vbMatched2 is declared but never set in either
+    int nmatches = 0;
+    for (int i = 0; i < n1; ++i) vMatches12[i] = -1;
+    RotHist rh;
+    const float factor = 1.0f / HISTO_LENGTH;                                 // :1441, :1672 (sic)
+    int a = 0, b = 0;
+    while (a < nn1 && b < nn2) {
+        if (nodes1[a] == nodes2[b]) {
+            for (int i1 = start1[a]; i1 < start1[a + 1]; ++i1) {
+                const int idx1 = idx1v[i1];
+                if (has_mp1[idx1]) continue;                                  // :1683-1685
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int i2 = start2[b]; i2 < start2[b + 1]; ++i2) {
+                    const int idx2 = idx2v[i2];
+                    if (has_mp2[idx2]) continue;                              // :1706-1707
+                    const int dist = orbref_hamming(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+                    if (dist > TH_LOW || dist > bestDist) continue;           // :1713-1715
+                    if (gate(user, idx1, idx2)) { bestIdx2 = idx2; bestDist = dist; }   // :1729-1733 / :1552-1556
+                }
+                if (bestIdx2 >= 0) {
+                    vMatches12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (check_ori) rh.add(kps1[idx1].angle, kps2[bestIdx2].angle, factor, idx1);
+                }
+            }
+            ++a; ++b;
+        } else if (nodes1[a] < nodes2[b]) {
+            a = (int)(std::lower_bound(nodes1, nodes1 + nn1, nodes2[b]) - nodes1);
+        } else {
+            b = (int)(std::lower_bound(nodes2, nodes2 + nn2, nodes1[a]) - nodes2);
+        }
+    }
+    if (check_ori) {
+        int ind[3];
+        rh.maxima(ind);
+        for (int bb = 0; bb < HISTO_LENGTH; ++bb) {
+            if (bb == ind[0] || bb == ind[1] || bb == ind[2]) continue;
+            for (int i : rh.bins[bb]) { vMatches12[i] = -1; nmatches--; }
+        }
+    }
+    (void)n2;
+    return nmatches;
+}
+
 int orbref_search_by_bow(int nkf, const orbref_kp_t* kps_kf, const uint8_t* desc_kf, const uint8_t* kf_good,
                          int nnk, const int32_t* nodes_k, const int32_t* start_k, const int32_t* idx_k,
                          int nf, const orbref_kp_t* kps_f, const uint8_t* desc_f,

@@ -415,6 +415,9 @@ class _CFrame(C.Structure):
                 ("grid_start", C.c_void_p), ("grid_idx", C.c_void_p)]
 
 
+PAIR_GATE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)      # orbm_pair_gate_fn (include/orbm.h)
+
+
 def _bind_search(L, prefix):
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     g = lambda n: getattr(L, prefix + n)
@@ -427,6 +430,7 @@ def _bind_search(L, prefix):
                                                   vp, cf, cf, vp, vp, ci, ci, ci, vp]
     g("search_by_bow").argtypes = h + [ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, cf, ci, vp]
     g("search_for_triangulation_legacy").argtypes = g("search_for_triangulation").argtypes
+    g("search_for_triangulation_gated").argtypes = h + [ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, PAIR_GATE, vp, ci, vp]
     g("search_by_projection_kf").argtypes = h + [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp]
     g("search_by_projection_sim3").argtypes = h + [vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, cf, vp]
     g("search_by_projection_frame_fisheye").argtypes = h + [vp, vp, vp, vp, vp, ci] + [vp] * 9 + [cf, ci, ci, ci, vp, vp]
@@ -616,6 +620,18 @@ class _SearchMixin:
                        _p(F), float(ep[0]), float(ep[1]), _p(sf2), _p(sg), int(only_stereo), int(coarse), int(check_ori), _p(m12))
         return n, m12
 
+    def SearchForTriangulationGated(self, k1, d1, has_mp1, fv1, k2, d2, has_mp2, fv2, gate, check_ori=False):
+        """M10 with a second camera / M12 (ORBmatcher.cc:1388-1629, 1632-1821): `gate(idx1, idx2) -> bool` stands for the
+        camera model's epipolarConstrain_ / matchAndtriangulate and is called where the reference calls it."""
+        m12 = np.full(len(k1), -1, np.int32)
+        k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)
+        d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        h1 = np.ascontiguousarray(has_mp1, np.uint8); h2 = np.ascontiguousarray(has_mp2, np.uint8)
+        cb = PAIR_GATE(lambda user, a, b: int(bool(gate(a, b))))
+        n = self._call("search_for_triangulation_gated", len(k1), _p(k1), _p(d1), _p(h1), len(fv1[0]), _p(fv1[0]), _p(fv1[1]), _p(fv1[2]),
+                       len(k2), _p(k2), _p(d2), _p(h2), len(fv2[0]), _p(fv2[0]), _p(fv2[1]), _p(fv2[2]), cb, None, int(check_ori), _p(m12))
+        return n, m12
+
     def SearchByBoW(self, kkf, dkf, kf_good, fvk, kf_, df, fvf, nnratio, check_ori=True):
         fm = np.full(len(kf_), -1, np.int32)
         kkf = np.ascontiguousarray(kkf); kf_ = np.ascontiguousarray(kf_)
@@ -634,7 +650,7 @@ def _install_search():
     L.orbm_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     for name in ("grid_build", "SearchByProjectionFrame", "SearchByProjectionPoints", "SearchForInitialization",
-                 "SearchForTriangulation", "SearchByBoW", "SearchByProjectionKF", "SearchByBoWKF", "SearchByProjectionSim3", "Fuse", "SearchBySim3", "SearchByProjectionFrameFisheye",
+                 "SearchForTriangulation", "SearchForTriangulationGated", "SearchByBoW", "SearchByProjectionKF", "SearchByBoWKF", "SearchByProjectionSim3", "Fuse", "SearchBySim3", "SearchByProjectionFrameFisheye",
                  "SearchByProjectionPointsFisheye", "SearchByBoWFisheye", "_call"):
         setattr(ORBmatcher, name, getattr(_SearchMixin, name))
     ORBmatcher._prefix = "orbm_"
@@ -736,7 +752,7 @@ def _frame_geometry_methods(prefix):
 EXPORTS += ["orbm_undistort_keypoints", "orbm_image_bounds", "orbm_is_in_frustum"]
 EXPORTS += ["orbm_grid_build", "orbm_window_candidates", "orbm_search_by_projection_frame", "orbm_search_by_projection_points",
             "orbm_search_for_initialization", "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_stereo_matches",
-            "orbm_search_by_projection_kf", "orbm_search_by_bow_kf", "orbm_search_for_triangulation_legacy",
+            "orbm_search_by_projection_kf", "orbm_search_by_bow_kf", "orbm_search_for_triangulation_legacy", "orbm_search_for_triangulation_gated",
             "orbm_search_by_projection_sim3", "orbm_fuse", "orbm_search_by_sim3",
             "orbm_grid_build_batch_async", "orbm_track_window_batch_async", "orbm_search_by_projection_frame_fisheye",
             "orbm_search_by_projection_points_fisheye", "orbm_search_by_bow_fisheye",

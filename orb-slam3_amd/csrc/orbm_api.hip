@@ -536,7 +536,8 @@ static int triangulation_impl(orbm_t* m, bool legacy, int n1, const orbm_kp_t* k
                                   int n2, const orbm_kp_t* kps2, const uint8_t* desc2, const uint8_t* has_mp2, const float* uright2,
                                   int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2,
                                   const float* F12, float epx, float epy, const float* sf2, const float* sigma2_2,
-                                  int bOnlyStereo, int bCoarse, int check_ori, int32_t* vMatches12) {
+                                  int bOnlyStereo, int bCoarse, int check_ori, int32_t* vMatches12,
+                                  orbm_pair_gate_fn gate = nullptr, void* gate_user = nullptr) {
     if (!m || n1 < 0 || n2 < 0) return ORBM_E_INVALID;
     std::vector<uint8_t> vbMatched2(n2, 0);                                 // only maintained by the legacy overload (:1319)
     JoinJobs J;
@@ -563,12 +564,13 @@ static int triangulation_impl(orbm_t* m, bool legacy, int n1, const orbm_kp_t* k
             const int d = dist[J.off[j] + c];
             if (d > ORBM_TH_LOW || d > bestDist) continue;
             const orbm_kp_t& kp2 = kps2[i2];
-            if (!bStereo1 && !bStereo2) {
+            if (!bStereo1 && !bStereo2 && sf2) {                            // sf2 == NULL: pKF1->mpCamera2 set (:1517) / M12, which has no such gate
                 const float distex = epx - kp2.x, distey = epy - kp2.y;
                 if (distex * distex + distey * distey < 100 * sf2[kp2.octave]) continue;
             }
             bool epi = false;
-            {   // Pinhole::epipolarConstrain_ (Pinhole.cpp:281-295)
+            if (gate) epi = gate(gate_user, i1, i2) != 0;                   // the caller's camera model, called where the reference calls it (:1552 / :1729)
+            else {   // Pinhole::epipolarConstrain_ (Pinhole.cpp:281-295)
                 const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
                 const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
                 const float c2 = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
@@ -614,6 +616,16 @@ int orbm_search_for_triangulation_legacy(orbm_t* m, int n1, const orbm_kp_t* kps
                                   int bOnlyStereo, int bCoarse, int check_ori, int32_t* vMatches12) {
     return triangulation_impl(m, true, n1, kps1, desc1, has_mp1, uright1, nn1, nodes1, start1, idx1, n2, kps2, desc2, has_mp2, uright2,
                               nn2, nodes2, start2, idx2, F12, epx, epy, sf2, sigma2_2, bOnlyStereo, bCoarse, check_ori, vMatches12);
+}
+
+int orbm_search_for_triangulation_gated(orbm_t* m, int n1, const orbm_kp_t* kps1, const uint8_t* desc1, const uint8_t* has_mp1,
+                                        int nn1, const int32_t* nodes1, const int32_t* start1, const int32_t* idx1,
+                                        int n2, const orbm_kp_t* kps2, const uint8_t* desc2, const uint8_t* has_mp2,
+                                        int nn2, const int32_t* nodes2, const int32_t* start2, const int32_t* idx2,
+                                        orbm_pair_gate_fn gate, void* user, int check_ori, int32_t* vMatches12) {
+    if (!gate) { set_merr("orbm_search_for_triangulation_gated needs a gate callback"); return ORBM_E_INVALID; }
+    return triangulation_impl(m, false, n1, kps1, desc1, has_mp1, nullptr, nn1, nodes1, start1, idx1, n2, kps2, desc2, has_mp2, nullptr,
+                              nn2, nodes2, start2, idx2, nullptr, 0.f, 0.f, nullptr, nullptr, 0, 0, check_ori, vMatches12, gate, user);
 }
 
 int orbm_search_by_projection_kf(orbm_t* m, const orbm_frame_t* cur, const uint8_t* blocked_in, const float* sf,

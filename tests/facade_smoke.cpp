@@ -1,9 +1,20 @@
 // Compiles the C++ facade against the minimal cv-compat layer and (on a GPU box) runs one extraction through it.
 #include <cstdio>
+#include <map>
 #include <vector>
 #include "../orb-slam3_amd/facade/ORBextractor.h"
 #include "../orb-slam3_amd/facade/ORBmatcher.h"
 #include "../orb-slam3_amd/facade/FrameGeometry.h"
+
+// the members of ORB_SLAM3::KeyFrame the triangulation searches read (include/KeyFrame.h)
+struct MockKeyFrame {
+    int N = 0, NLeft = -1;
+    std::vector<cv::KeyPoint> mvKeysUn, mvKeys, mvKeysRight;
+    cv::Mat mDescriptors;
+    std::map<unsigned, std::vector<unsigned>> mFeatVec;
+    std::vector<void*> mps;
+    void* GetMapPoint(int i) { return mps[i]; }
+};
 
 int main(int argc, char** argv) {
     const int w = 752, h = 480;
@@ -35,6 +46,25 @@ int main(int argc, char** argv) {
         const float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0}, O[3] = {0, 0, 0}, b[4] = {x0, x1, y0, y1};
         const int nin = ORB_SLAM3::IsInFrustumBatch(m.handle(), {0.f, 0.f, 4.f}, {0.f, 0.f, 1.f}, {0.5f}, {6.f}, R, t, O, K, b, 47.9f, 0.5f, 0.18232156f, 8, fo);
         if (nin != 1 || fo.level[0] < 0) return 6;
+    }
+    {   // M10-with-two-cameras / M12 bucket search: a frame matched against itself under a gate that forbids the identity pair
+        MockKeyFrame a, b;
+        const int n = (int)kps.size();
+        const int nl = n / 2;
+        for (MockKeyFrame* kf : {&a, &b}) {
+            kf->N = n; kf->NLeft = nl; kf->mDescriptors = desc; kf->mps.assign(n, nullptr);
+            kf->mvKeys.assign(kps.begin(), kps.begin() + nl); kf->mvKeysRight.assign(kps.begin() + nl, kps.end());
+            for (int i = 0; i < n; ++i) kf->mFeatVec[desc.ptr(i)[0] & 15].push_back(i);
+        }
+        std::vector<std::pair<size_t, size_t>> pairs;
+        int calls = 0;
+        ORB_SLAM3::ORBmatcher mt(0.6f, false);
+        const int all = mt.SearchForTriangulationGated(&a, &b, [&](int, int) { ++calls; return true; }, pairs);
+        if (all != n || (int)pairs.size() != n) return 7;             // distance 0 to itself: every feature keeps a match
+        for (auto& pr : pairs) if (orbm_hamming(desc.ptr((int)pr.first), desc.ptr((int)pr.second)) != 0) return 8;
+        const int off = mt.SearchForTriangulationGated(&a, &b, [&](int i1, int i2) { return i1 != i2; }, pairs);
+        for (auto& pr : pairs) if (pr.first == pr.second) return 9;
+        std::printf("facade: gated triangulation search %d / %d matches, %d gate calls\n", all, off, calls);
     }
     return 0;
 }

@@ -189,6 +189,37 @@ def test_search_for_triangulation_legacy(pkg, scene, bits, coarse, ori):
         assert len(np.unique(taken)) == len(taken)          # vbMatched2 keeps the matching one-to-one
 
 
+@pytest.mark.parametrize("bits,accept,ori", [(5, 0.5, True), (6, 0.8, False), (3, 0.3, True), (4, 1.0, True), (4, 0.0, False)])
+def test_search_for_triangulation_gated(pkg, scene, bits, accept, ori):
+    # M10 with a second camera / M12 (ORBmatcher.cc:1632-1821): the camera model's gate is the caller's; a seeded
+    # pseudo-random predicate of the pair stands in for KannalaBrandt8::epipolarConstrain_ / matchAndtriangulate.  The gate
+    # must be consulted for the same pairs in the same order as by the reference loop (a stateful gate — M12's x3D — sees
+    # the same history), and the selected matches must agree.
+    rng = np.random.default_rng(bits + 700)
+    kl, kr, dl, dr = scene["kl"], scene["kr"], scene["dl"], scene["dr"]
+    table = rng.random((257, 263)) < accept
+    args = dict(k1=kl, d1=dl, has_mp1=rng.random(len(kl)) < 0.3, fv1=_fv(pkg, dl, bits), k2=kr, d2=dr,
+                has_mp2=rng.random(len(kr)) < 0.3, fv2=_fv(pkg, dr, bits), check_ori=ori)
+    calls = ([], [])
+    out = []
+    for b, log in zip((scene["m"], scene["OM"]), calls):
+        def gate(i1, i2, log=log):
+            log.append((i1, i2))
+            return table[i1 % 257, i2 % 263]
+        out.append(b.SearchForTriangulationGated(gate=gate, **args))
+    assert calls[0] == calls[1] and len(calls[1]) > 50
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    if accept == 0.0:
+        assert out[1][0] == 0
+    if accept == 1.0:
+        assert out[1][0] > 10
+        last = {}
+        for i1, i2 in calls[1]:
+            last[i1] = i2                                    # every accepted call replaces the best: the last one wins
+        if not ori:
+            assert all(out[1][1][i1] == i2 for i1, i2 in last.items())
+
+
 @pytest.mark.parametrize("th,ratio", [(8, 1.5), (4, 1.0), (15, 2.0)])
 def test_search_by_projection_sim3(pkg, scene, th, ratio):
     # loop closing: LoopClosing.cc uses th = 8, ratioHamming = 1.5 for the Sim3 guided search

@@ -210,6 +210,32 @@ def test_undistort_and_frustum_known_answers(oracle, pkg):
     assert o["proj_x"][1] == -1.0 and o["proj_x"][2] == -1.0 and o["proj_x"][3] == 320.0   # bounds test passed before the later rejects
 
 
+def test_triangulation_gated_known_answers(oracle, pkg):
+    # hand-built case for ORBmatcher.cc:1632-1821: one shared vocabulary node, three KF1 features, four KF2 features.
+    # dist <= TH_LOW (50) and dist <= bestDist gate the callback; later candidates win ties (`dist > bestDist` rejects).
+    ref = oracle._oracle_matcher_class()()
+    kp = np.zeros(4, pkg.KP_DTYPE)
+    d1 = np.zeros((3, 32), np.uint8)
+    d2 = np.zeros((4, 32), np.uint8)
+    d2[0, :2] = 0xFF                                   # 16 bits from d1[*]
+    d2[1, :1] = 0xFF                                   # 8 bits
+    d2[2, :1] = 0x0F; d2[2, 1] = 0x0F                  # 8 bits as well: a tie with d2[1], later index wins
+    d2[3, :7] = 0xFF                                   # 56 bits > TH_LOW: never reaches the gate
+    fv1 = pkg.feature_vector_csr(np.array([5, 5, 9]))  # feature 2 sits in a node KF2 does not have
+    fv2 = pkg.feature_vector_csr(np.array([5, 5, 5, 5]))
+    calls = []
+    def gate(i1, i2):
+        calls.append((i1, i2))
+        return not (i1 == 1 and i2 == 2)               # feature 1 may not take candidate 2
+    n, m = ref.SearchForTriangulationGated(kp[:3], d1, [0, 0, 0], fv1, kp, d2, [0, 0, 0, 0], fv2, gate)
+    assert n == 2 and m.tolist() == [2, 1, -1]
+    assert calls == [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2)]
+    # MapPoints on either side take features out before any distance is looked at
+    calls.clear()
+    n, m = ref.SearchForTriangulationGated(kp[:3], d1, [1, 0, 0], fv1, kp, d2, [0, 1, 0, 0], fv2, gate)
+    assert n == 1 and m.tolist() == [-1, 0, -1] and calls == [(1, 0), (1, 2)]
+
+
 def test_gray_from_color_known_answers(oracle):
     """OpenCV's RGB2Gray<uchar> fixed point: coefficients sum to 1 << bits, so gray levels map to themselves."""
     for bits, (ry, gy, by) in ((14, (4899, 9617, 1868)), (15, (9798, 19235, 3735))):
