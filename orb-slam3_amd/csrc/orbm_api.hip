@@ -117,7 +117,12 @@ int orbm_knn2_batch_async(orbm_t* m, const uint8_t* q, int q_stride, const int32
     MHIPCHK(hipSetDevice(m->device));
     m->gridFirst = false;
     MHIPCHK(hipEventRecord(m->e0, m->stream));
-    hipLaunchKernelGGL(k_knn2, dim3((q_stride + 63) / 64, npairs), dim3(256), 0, m->stream, q, q_stride, nq, t, t_stride, nt, idx2, dist2);
+    // matrix-core kernel unless the train set is beyond its 19-bit row field (or ORBM_KNN2_VALU asks for the popcount kernel: A/B)
+    const bool forceValu = getenv("ORBM_KNN2_VALU") != nullptr;   // read per call: tests flip it
+    if (t_stride <= KM_MAX_NT && !forceValu)
+        hipLaunchKernelGGL(k_knn2_mfma, dim3((q_stride + 255) / 256, npairs), dim3(256), 0, m->stream, q, q_stride, nq, t, t_stride, nt, idx2, dist2);
+    else
+        hipLaunchKernelGGL(k_knn2, dim3((q_stride + 63) / 64, npairs), dim3(256), 0, m->stream, q, q_stride, nq, t, t_stride, nt, idx2, dist2);
     MHIPCHK(hipEventRecord(m->e1, m->stream));
     MHIPCHK(hipGetLastError());
     m->timed = true;

@@ -108,6 +108,131 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int
 
 
 // ------------------------------------------------------------------------------------------------
+// k_knn2_mfma: the same dense 2-NN on the matrix cores.  A 1000 x 1000 x 256-bit Hamming table is O(n^2) integer work
+// on 64 KB of operands -- compute bound, the one GEMM-shaped piece of the path -- and it is exact in int8:
+//   ham(q, t) = popc(q) + sum_k t_k * (1 - 2 q_k)            (t_k, q_k the descriptor bits)
+// so with train bits as 0/1 bytes in the A operand and query bits as +-1 bytes in the B operand, v_mfma_i32_32x32x32_i8
+// accumulates ham - popc(q) for 32 train rows x 32 query columns; popc(q) is constant per column and is added at the end.
+// Bit -> byte expansion is one v_and per operand dword: dword e of a lane's fragment = (w >> 4h) & (0x01010101 << e), i.e.
+// bytes worth 0 or 2^e, and the query side carries the matching +-2^(3-e), so every product is +-8 and the accumulator
+// is 8 * (ham - popc(q)).  Which k each (lane half h, byte) lands on does not matter: A and B use the same map.
+// Selection without leaving the accumulator layout (column = lane & 31 = query, 16 train rows per lane): the accumulator
+// starts at C = (row << 13) + 2048, so rotating the result right by 13 gives the packed key (8*ham' + 2048) << 19 | row,
+// whose unsigned order is (distance, train index) -- the reference's tie rule -- and one v_min + one v_med3 keep the two
+// smallest.  Rows are tile-relative: tiles are walked from the last to the first and the kept keys move up by 32 per tile.
+// A wave owns 64 queries (two B fragments sets) and streams the pair's train descriptors from L2; no LDS, no barrier.
+// Limits (host-checked): t_stride <= KM_MAX_NT.
+// ------------------------------------------------------------------------------------------------
+#define KM_MAX_NT ((1 << 19) - 64)
+typedef int km_i32x4 __attribute__((ext_vector_type(4)));
+typedef int km_i32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t* __restrict__ q, int q_stride, const int* __restrict__ nq,
+                                                   const uint8_t* __restrict__ t, int t_stride, const int* __restrict__ nt,
+                                                   int* __restrict__ idx2, int* __restrict__ dist2) {
+#if __HIP_DEVICE_COMPILE__
+    const int pair = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nQ = nq[pair], nT = nt[pair];
+    const int q0 = blockIdx.x * 256 + wv * 64;
+    if (q0 >= nQ) return;                                     // wave-uniform; the kernel has no barrier
+    const int r = lane & 31, h = lane >> 5;
+    const unsigned SENT = 0xFFF80000u;                        // distance field all ones: "no neighbour"
+    // ---- query side: +-2^(3-e) bytes, built once
+    km_i32x4 bf[2][8];
+    int pq[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int qi = q0 + n * 32 + r;
+        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+        if (qi < nQ) {
+            const uint4* qp = (const uint4*)(q + ((size_t)pair * q_stride + qi) * 32);
+            lo = qp[0]; hi = qp[1];
+        }
+        const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        int pc = 0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            pc += __popc(w[s]);
+            const unsigned wp = w[s] >> (4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned y = (wp >> e) & 0x01010101u;              // the bit, per byte
+                const unsigned mag = 8u >> e;
+                bf[n][s][e] = (int)(mag * 0x01010101u + y * (256u - 2u * mag));   // bit ? -mag : +mag as int8 (no carries: <= 255 per byte)
+            }
+        }
+        pq[n] = pc;
+    }
+    km_i32x16 cin;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cin[i] = ((((i & 3) + 8 * (i >> 2) + 4 * h)) << 13) + 2048;
+    unsigned k0[2] = {SENT, SENT}, k1[2] = {SENT, SENT};
+    const uint8_t* tb = t + (size_t)pair * t_stride * 32;
+    const int ntile = (nT + 31) >> 5;
+    uint4 nlo = make_uint4(0, 0, 0, 0), nhi = nlo;
+    if (ntile > 0 && (ntile - 1) * 32 + r < nT) {
+        const uint4* tp = (const uint4*)(tb + (size_t)((ntile - 1) * 32 + r) * 32);
+        nlo = tp[0]; nhi = tp[1];
+    }
+    for (int tile = ntile - 1; tile >= 0; --tile) {
+        const uint4 lo = nlo, hi = nhi;
+        if (tile > 0) {                                       // the next tile is always a full one
+            const uint4* tp = (const uint4*)(tb + (size_t)((tile - 1) * 32 + r) * 32);
+            nlo = tp[0]; nhi = tp[1];
+        }
+        const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        km_i32x16 acc0 = cin, acc1 = cin;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const unsigned wp = w[s] >> (4 * h);
+            km_i32x4 a;
+            a[0] = (int)(wp & 0x01010101u); a[1] = (int)(wp & 0x02020202u); a[2] = (int)(wp & 0x04040404u); a[3] = (int)(wp & 0x08080808u);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[0][s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[1][s], acc1, 0, 0, 0);
+        }
+        k0[0] += 32u; k1[0] += 32u; k0[1] += 32u; k1[1] += 32u;          // kept keys become relative to this tile's first row
+        if (tile * 32 + 32 <= nT) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const unsigned ka = __builtin_amdgcn_alignbit((unsigned)acc0[i], (unsigned)acc0[i], 13);
+                const unsigned kb = __builtin_amdgcn_alignbit((unsigned)acc1[i], (unsigned)acc1[i], 13);
+                k1[0] = umed3(k0[0], k1[0], ka); k0[0] = min(k0[0], ka);
+                k1[1] = umed3(k0[1], k1[1], kb); k0[1] = min(k0[1], kb);
+            }
+        } else {                                              // the ragged last tile: rows past nT are not candidates
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool ok = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h < nT;
+                const unsigned ka = ok ? __builtin_amdgcn_alignbit((unsigned)acc0[i], (unsigned)acc0[i], 13) : SENT;
+                const unsigned kb = ok ? __builtin_amdgcn_alignbit((unsigned)acc1[i], (unsigned)acc1[i], 13) : SENT;
+                k1[0] = umed3(k0[0], k1[0], ka); k0[0] = min(k0[0], ka);
+                k1[1] = umed3(k0[1], k1[1], kb); k0[1] = min(k0[1], kb);
+            }
+        }
+    }
+    // ---- the two lane halves saw disjoint train rows of the same query: merge, then half h stores query set h
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const unsigned o0 = (unsigned)__shfl_xor((int)k0[n], 32), o1 = (unsigned)__shfl_xor((int)k1[n], 32);
+        k1[n] = umed3(k0[n], k1[n], o0); k0[n] = min(k0[n], o0);
+        k1[n] = umed3(k0[n], k1[n], o1); k0[n] = min(k0[n], o1);
+    }
+    const unsigned f0 = h ? k0[1] : k0[0], f1 = h ? k1[1] : k1[0];
+    const int pqs = h ? pq[1] : pq[0];
+    const int qi = q0 + h * 32 + r;
+    if (qi < nQ) {
+        const size_t o = ((size_t)pair * q_stride + qi) * 2;
+        const bool h0 = (f0 >> 19) != 0x1FFFu, h1 = (f1 >> 19) != 0x1FFFu;
+        idx2[o] = h0 ? (int)(f0 & 0x7FFFFu) : -1; idx2[o + 1] = h1 ? (int)(f1 & 0x7FFFFu) : -1;
+        dist2[o] = h0 ? (((int)(f0 >> 19) - 2048) >> 3) + pqs : -1;
+        dist2[o + 1] = h1 ? (((int)(f1 >> 19) - 2048) >> 3) + pqs : -1;
+    }
+#endif
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // k_grid_build: Frame::AssignFeaturesToGrid (Frame.cc:446-480).  One workgroup per frame.
 // Stable order inside a cell = ascending keypoint index: sort keys (cell<<16 | index) with a bitonic
 // sort in LDS, then every cell finds its start with a binary search.

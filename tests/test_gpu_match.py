@@ -19,6 +19,51 @@ def test_knn2_random(pkg, oracle, nq, nt):
     assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
 
 
+@pytest.mark.parametrize("nq,nt", [(31, 31), (32, 32), (33, 33), (63, 65), (255, 95), (256, 96), (257, 97), (1000, 1000), (1, 4100)])
+def test_knn2_tile_edges_and_both_kernels(pkg, oracle, monkeypatch, nq, nt):
+    # k_knn2_mfma works on 32 x 32 tiles, 64 queries per wave, 256 per workgroup, train tiles walked last to first with a
+    # ragged last tile; k_knn2 (ORBM_KNN2_VALU) is the popcount kernel it replaced.  Both must equal the oracle.
+    rng = np.random.default_rng(nq * 31 + nt)
+    q, t = _rand_desc(rng, nq), _rand_desc(rng, nt)
+    q[0] = 0; q[-1] = 255                                        # popcount 0 / 256 queries
+    t[0] = 255; t[-1] = 0                                        # distances 0 and 256 occur
+    if nt > 40:
+        t[nt - 3] = t[5]                                         # equal distances far apart: lower index first
+    ridx, rdist = oracle.knn2(q, t)
+    m = pkg.ORBmatcher()
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("ORBM_KNN2_VALU", "1")
+        idx, dist = m.knn2(q, t)
+        assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), "valu" if force else "mfma"
+    assert rdist.min() == 0
+    # the extreme distances themselves: two train rows, all ones and all zeros
+    t2 = np.stack([np.full(32, 255, np.uint8), np.zeros(32, np.uint8)])
+    i2, d2 = m.knn2(np.stack([np.zeros(32, np.uint8), np.full(32, 255, np.uint8)]), t2)
+    assert i2.tolist() == [[1, 0], [0, 1]] and d2.tolist() == [[0, 256], [0, 256]]
+
+
+def test_knn2_batch_ragged_pairs(pkg, oracle):
+    # several pairs in one launch, each with its own counts inside fixed strides (the bench / fisheye-stereo layout)
+    rng = np.random.default_rng(99)
+    import ctypes as C
+    nqs, nts = [100, 0, 257, 64, 300], [333, 50, 1, 0, 300]
+    qs, ts = 320, 352
+    P = len(nqs)
+    q = rng.integers(0, 256, (P, qs, 32), dtype=np.uint8); t = rng.integers(0, 256, (P, ts, 32), dtype=np.uint8)
+    m = pkg.ORBmatcher()
+    idx = np.full((P, qs, 2), -7, np.int32); dist = np.full((P, qs, 2), -7, np.int32)
+    nq = np.array(nqs, np.int32); nt = np.array(nts, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = m.L.orbm_knn2_batch(m.h, pkg.HOST, p(q), qs, p(nq), p(t), ts, p(nt), P, p(idx), p(dist))
+    assert rc == 0, m.L.orbm_last_error()
+    for i in range(P):
+        if nqs[i] == 0:
+            continue
+        ridx, rdist = oracle.knn2(q[i, :nqs[i]], t[i, :nts[i]])
+        assert np.array_equal(idx[i, :nqs[i]], ridx) and np.array_equal(dist[i, :nqs[i]], rdist), i
+
+
 def test_knn2_ties_take_lower_index(pkg, oracle):
     rng = np.random.default_rng(3)
     base = _rand_desc(rng, 40)
