@@ -42,6 +42,8 @@ struct orbx {
     Geom g;
     std::vector<CellInfo> cells;
     std::vector<BlurTask> tiles;
+    std::vector<Blur3Task> tiles3;                            // k_blur3 (matrix-core blur) tasks
+    std::vector<u32> b3Th, b3Tv;                              // its weight fragments: [strip][2][64][4], [tile row][64][4]
     BlurSel blurSel;
     std::vector<StripInfo> strips;
     StripInfo* dStrips = nullptr; size_t capStrips = 0;
@@ -60,7 +62,7 @@ struct orbx {
     int64_t algBytes = 0, fusedBytes = 0;
     size_t qtLds = 0, qt2Lds = 0;
     int qt2Cap = 0, qt2Sort = 0;
-    bool qtV1 = false, odV1 = false, serial = false;
+    bool qtV1 = false, odV1 = false, serial = false, blurV2 = true;
     bool qtWide = false;                                       // 1024-thread quadtree workgroups (large frames / feature counts)
     int qtWideForce = -1;                                      // ORBX_QT_WIDE=0/1: A/B switch
     // device
@@ -73,6 +75,8 @@ struct orbx {
     long nEnq = 0;
     u8 *dPyr = nullptr, *dBlur = nullptr, *dL0 = nullptr;
     const u8** dL0Ptr = nullptr;
+    Blur3Task* dTiles3 = nullptr; size_t capTiles3 = 0;
+    u32 *dB3Th = nullptr, *dB3Tv = nullptr; size_t capB3Th = 0, capB3Tv = 0;
     CellInfo* dCells = nullptr; BlurTask* dTiles = nullptr; RzTab *dXt = nullptr, *dYt = nullptr;
     u32 *dCandCnt = nullptr, *dCandEnt = nullptr, *dSel = nullptr, *dSelCnt = nullptr;
     u16* dKpNode = nullptr;
@@ -115,7 +119,7 @@ static int build_geometry(orbx* o, int w, int h) {
     memset(&g, 0, sizeof g);
     const int L = o->nlevels;
     g.nlevels = L; g.w0 = w; g.h0 = h; g.iniTh = o->iniTh; g.minTh = o->minTh; g.lowTh = std::min(o->iniTh, o->minTh);
-    o->cells.clear(); o->tiles.clear(); o->strips.clear(); o->f3g.clear(); o->stripTile.clear(); o->stripQ.clear(); o->xt.clear(); o->yt.clear(); o->x4.clear(); for (auto& v : o->rzTasks) v.clear();
+    o->cells.clear(); o->tiles.clear(); o->tiles3.clear(); o->b3Th.clear(); o->b3Tv.clear(); o->strips.clear(); o->f3g.clear(); o->stripTile.clear(); o->stripQ.clear(); o->xt.clear(); o->yt.clear(); o->x4.clear(); for (auto& v : o->rzTasks) v.clear();
     size_t off = 0;
     int totalSlots = 0, totalSel = 0, maxN = 0;
     int64_t sumAll = 0, sumSrc = 0, sumDst = 0;
@@ -218,6 +222,18 @@ static int build_geometry(orbx* o, int w, int h) {
                     g0 = lastOut + 1;
                 }
         }
+        {   // k_blur3: one wavefront per 32-px column strip and chunk of up to B3_CHUNK 26-row tiles; weight fragments per
+            // strip (pass 1, reflect-101 folded at the left / right edge) and per tile row (pass 2, folded at top / bottom)
+            const int ntile = (D.h + B3_ROWS - 1) / B3_ROWS, nstrip = (D.w + 31) / 32;
+            const int th0 = (int)(o->b3Th.size() / 512), tv0 = (int)(o->b3Tv.size() / 256);
+            o->b3Th.resize(o->b3Th.size() + (size_t)nstrip * 512);
+            o->b3Tv.resize(o->b3Tv.size() + (size_t)ntile * 256);
+            for (int sx = 0; sx < nstrip; ++sx) b3_build_th(sx * 32, D.w, o->b3Th.data() + (size_t)(th0 + sx) * 512);
+            for (int t = 0; t < ntile; ++t) b3_build_tv(t * B3_ROWS, D.h, o->b3Tv.data() + (size_t)(tv0 + t) * 256);
+            for (int t0 = 0; t0 < ntile; t0 += B3_CHUNK)
+                for (int sx = 0; sx < nstrip; sx += 4)                  // a workgroup = four adjacent strips
+                    o->tiles3.push_back(Blur3Task{(short)l, (short)(sx * 32), (short)t0, (short)std::min(B3_CHUNK, ntile - t0), th0 + sx, tv0 + t0});
+        }
         {
             static const u32 kSelB[4] = {0x05060700u, 0x07000100u, 0x01020100u, 0x03020100u};   // k = (w-1)&3 valid bytes-1
             static const u32 kSelC[4] = {0x04040404u, 0x04040506u, 0x05060700u, 0x07000102u};
@@ -319,6 +335,9 @@ static int build_geometry(orbx* o, int w, int h) {
     if (ensure(&o->dL0, &o->capL0, (size_t)o->l0pitch * h * B)) return ORBX_E_HIP;
     if (ensure(&o->dCells, &o->capCells, o->cells.size())) return ORBX_E_HIP;
     if (ensure(&o->dTiles, &o->capTiles, o->tiles.size())) return ORBX_E_HIP;
+    if (ensure(&o->dTiles3, &o->capTiles3, o->tiles3.size())) return ORBX_E_HIP;
+    if (ensure(&o->dB3Th, &o->capB3Th, o->b3Th.size())) return ORBX_E_HIP;
+    if (ensure(&o->dB3Tv, &o->capB3Tv, o->b3Tv.size())) return ORBX_E_HIP;
     if (ensure(&o->dStrips, &o->capStrips, o->strips.size())) return ORBX_E_HIP;
     if (ensure(&o->dXt, &o->capXt, std::max<size_t>(1, o->xt.size()))) return ORBX_E_HIP;
     if (ensure(&o->dYt, &o->capYt, std::max<size_t>(1, o->yt.size()))) return ORBX_E_HIP;
@@ -344,6 +363,9 @@ static int build_geometry(orbx* o, int w, int h) {
     }
     HIPCHK(hipMemcpy(o->dCells, o->cells.data(), o->cells.size() * sizeof(CellInfo), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(o->dTiles, o->tiles.data(), o->tiles.size() * sizeof(BlurTask), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(o->dTiles3, o->tiles3.data(), o->tiles3.size() * sizeof(Blur3Task), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(o->dB3Th, o->b3Th.data(), o->b3Th.size() * sizeof(u32), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(o->dB3Tv, o->b3Tv.data(), o->b3Tv.size() * sizeof(u32), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(o->dStrips, o->strips.data(), o->strips.size() * sizeof(StripInfo), hipMemcpyHostToDevice));
     if (!o->xt.empty()) HIPCHK(hipMemcpy(o->dXt, o->xt.data(), o->xt.size() * sizeof(RzTab), hipMemcpyHostToDevice));
     if (!o->yt.empty()) HIPCHK(hipMemcpy(o->dYt, o->yt.data(), o->yt.size() * sizeof(RzTab), hipMemcpyHostToDevice));
@@ -425,6 +447,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     o->maxW = max_w; o->maxH = max_h; o->maxBatch = max_batch;
     o->fastV1 = getenv("ORBX_FAST_V1") != nullptr;
     o->qtV1 = getenv("ORBX_QT_V1") != nullptr;
+    o->blurV2 = getenv("ORBX_BLUR_MFMA") == nullptr;         // default: the VALU blur (k_blur2); ORBX_BLUR_MFMA selects the matrix-core k_blur3 (A/B)
     o->odV1 = getenv("ORBX_OD_V1") != nullptr;
     if (const char* e = getenv("ORBX_FAST_QCAP")) o->f3QcapForce = atoi(e);
     if (const char* e = getenv("ORBX_QT_WIDE")) o->qtWideForce = atoi(e) != 0 ? 1 : 0;
@@ -487,7 +510,7 @@ void orbx_destroy(orbx_t* o) {
     (void)hipSetDevice(o->device);
     if (o->stream) (void)hipStreamSynchronize(o->stream);
     if (o->stream2) (void)hipStreamSynchronize(o->stream2);
-    void* ptrs[] = {o->dPyr, o->dBlur, o->dL0, (void*)o->dL0Ptr, o->dCells, o->dTiles, o->dStrips, o->dX4, o->dRzTasks, o->dXt, o->dYt, o->dCandCnt, o->dCandEnt,
+    void* ptrs[] = {o->dPyr, o->dBlur, o->dL0, (void*)o->dL0Ptr, o->dCells, o->dTiles, o->dTiles3, o->dB3Th, o->dB3Tv, o->dStrips, o->dX4, o->dRzTasks, o->dXt, o->dYt, o->dCandCnt, o->dCandEnt,
                     o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->dKps, o->dDesc, o->dWork, o->dN, o->dMono, o->dLap, o->dErr, o->dPattern, o->dOvf, o->dOvfList, o->dOdW};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& set : o->evr) for (auto& e : set) if (e) (void)hipEventDestroy(e);
@@ -619,8 +642,12 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     // blur (VALU + HBM) runs beside the quadtree (LDS-latency bound), not beside FAST (VALU bound)
     if (!o->serial) HIPCHK(hipStreamWaitEvent(s1, o->ev[2], 0));
     STAGE_EV(11, s1);
-    hipLaunchKernelGGL(k_blur2, dim3((unsigned)(o->tiles.size() + 3) / 4, nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
-                       o->dTiles, (int)o->tiles.size(), o->blurSel);
+    if (o->blurV2)
+        hipLaunchKernelGGL(k_blur2, dim3((unsigned)(o->tiles.size() + 3) / 4, nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
+                           o->dTiles, (int)o->tiles.size(), o->blurSel);
+    else
+        hipLaunchKernelGGL(k_blur3, dim3((unsigned)o->tiles3.size(), nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
+                           o->dTiles3, (const uint4*)o->dB3Th, (const uint4*)o->dB3Tv);
     HIPCHK(hipEventRecord(o->ev[9], s1));                        // blur ready
     if (o->qtV1)
         hipLaunchKernelGGL(k_quadtree, dim3(nimg, g.nlevels), dim3(256), o->qtLds, st, g, o->dCells, o->dCandCnt, o->dCandEnt,

@@ -1229,6 +1229,213 @@ __device__ __forceinline__ int reflect101(int p, int n) {   // valid for -n < p 
 // DPP wave_shr/wave_shl (one VALU op, no LDS), horizontal 7-tap as two v_dot4_u32_u8 per pixel, then the vertical 7-tap
 // as four v_dot2_u32_u16 over a rotating 7-row register window of (previous row, row) sums.  Reflect-101 at the left/right image edge is done with v_perm selectors chosen on
 // the host from (width & 3); rows reflect through the row index.
+// ------------------------------------------------------------------------------------------------
+// k_blur3: the same blur on the matrix cores.  Both passes are small integer matrix products with banded (Toeplitz)
+// weight matrices, and the arithmetic is exact in int8 x int8 -> int32:
+//   pass 1   H[32 rows][32 cols] = X[32 rows][64 px] . Th[64 px][32 cols]      (2 x v_mfma_i32_32x32x32_i8)
+//            X as (pixel - 128): one 16-byte row load + 4 v_xor per lane and k-step; Th[p][c] = sum of the taps whose
+//            reflect-101 source pixel for output column c is p (7 taps, sum 256), so the accumulator started at 32768 holds
+//            the reference's Q8.8 row sum (<= 65280) exactly, borders included.
+//   pass 2   V = Tv[32 out rows][32 H rows] . H   with H split into its low and high bytes (2 MFMAs): the accumulator tile
+//            of pass 1 (column on the lane, 16 rows in the registers) IS the B operand layout of a product that sums over
+//            its rows -- 4 v_perm gather the bytes of 4 registers, no lane movement, no LDS; Tv carries the k order of the
+//            accumulator registers.  out = ((accHi << 8) + accLo) >> 16 with the -128 offsets and the +32768 rounding folded
+//            into accLo's start value.
+// A tile yields 26 output rows from 32 source rows (3-row aprons recomputed: 23 % more pass-1 work, no state between tiles).
+// A workgroup owns a 128-px column group (one 32-px block per wave) and walks up to B3_CHUNK tiles down it; the 32 x 160 B
+// source window of a tile is staged through LDS with full-line loads, double-buffered, one barrier per tile (the A-operand
+// layout wants 16 bytes of a different row in every lane: read straight from memory that is 32-byte pieces of 128-byte
+// lines and the kernel ran at the L2's line rate, 0.72 ms).  The weight fragments depend only on the
+// geometry -- Th on (level, strip), Tv on (level, tile row) -- and are tabulated by the host in fragment order when the
+// geometry is built (built in the kernel they cost more than the tiles themselves); border folds are just table entries.
+// ------------------------------------------------------------------------------------------------
+#define B3_ROWS 26
+#define B3_CHUNK 4
+struct Blur3Task { short level, x0, t0, nt; int th, tv; };   // th / tv: entries of the weight tables (tv: of tile t0)
+typedef int b3_i32x4 __attribute__((ext_vector_type(4)));
+typedef int b3_i32x16 __attribute__((ext_vector_type(16)));
+
+// weight of source position p in output position `out` of an n-long line: sum_i [reflect101(out + i - 3) == p] * K[i]
+// (host side: the weight fragments are tabulated per column strip and per tile row when the geometry is built)
+static inline int b3_toep(int p, int out, int n) {
+    const int K[7] = {18, 34, 48, 56, 48, 34, 18};
+    int wsum = 0;
+    for (int i = 0; i < 7; ++i) {
+        int q = out + i - 3;
+        q = q < 0 ? -q : q;
+        q = q >= n ? 2 * n - 2 - q : q;
+        wsum += q == p ? K[i] : 0;
+    }
+    return wsum;
+}
+// pass-1 weights (B operand) of the strip at x0: [k-step s][lane] uint4; lane (r, hh) holds column x0 + r, element j of
+// k-step s <-> pixel x0 - 16 + 32 s + 16 hh + j
+static inline void b3_build_th(int x0, int w, u32* out /* [2][64][4] */) {
+    for (int s = 0; s < 2; ++s)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 4; ++e) {
+                const int r = lane & 31, hh = lane >> 5;
+                u32 v = 0;
+                for (int b = 0; b < 4; ++b) v |= (u32)b3_toep(x0 - 16 + 32 * s + 16 * hh + 4 * e + b, x0 + r, w) << (8 * b);
+                out[(s * 64 + lane) * 4 + e] = v;
+            }
+}
+// pass-2 weights (A operand) of the tile at y0: [lane] uint4; lane (r, hh) holds output row y0 + r (26 valid), element j <->
+// H row (j&3) + 8 (j>>2) + 4 hh of the tile = image row y0 - 3 + that (the register order of the pass-1 accumulator)
+static inline void b3_build_tv(int y0, int h, u32* out /* [64][4] */) {
+    for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 4; ++e) {
+            const int r = lane & 31, hh = lane >> 5;
+            u32 v = 0;
+            for (int b = 0; b < 4; ++b) {
+                const int j = 4 * e + b, krow = (j & 3) + 8 * (j >> 2) + 4 * hh;
+                v |= (r < B3_ROWS ? (u32)b3_toep(y0 - 3 + krow, y0 + r, h) : 0u) << (8 * b);
+            }
+            out[lane * 4 + e] = v;
+        }
+}
+
+#define B3_OROW 144                                        // output staging row stride (128 B + 16 B pad)
+#define B3_LROW 176                                        // LDS row stride: 160 B of pixels + 16 B pad (b128 reads conflict-free)
+__global__ __launch_bounds__(256) void k_blur3(Geom g, const u8* const* l0, int l0pitch, const u8* pyr, u8* blr,
+                                               const Blur3Task* __restrict__ tasks,
+                                               const uint4* __restrict__ thTab, const uint4* __restrict__ tvTab) {
+#if __HIP_DEVICE_COMPILE__
+    __shared__ __attribute__((aligned(16))) u8 xs[2][32 * B3_LROW];
+    __shared__ __attribute__((aligned(16))) u8 ob[2][32 * B3_OROW];   // blurred tile of the workgroup, 32 rows x 128 px
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int cb = __builtin_amdgcn_readfirstlane(tid >> 6);            // this wave's 32-px column block of the 128-px group
+    Blur3Task t = tasks[blockIdx.x];                                    // one task per workgroup: (level, 128-px group, tile chunk)
+    t.level = (short)__builtin_amdgcn_readfirstlane(t.level);
+    t.x0 = (short)__builtin_amdgcn_readfirstlane(t.x0);
+    t.t0 = (short)__builtin_amdgcn_readfirstlane(t.t0);
+    t.nt = (short)__builtin_amdgcn_readfirstlane(t.nt);
+    t.th = __builtin_amdgcn_readfirstlane(t.th);
+    t.tv = __builtin_amdgcn_readfirstlane(t.tv);
+    const int frame = blockIdx.y;
+    const LevelDesc& L = g.lv[t.level];
+    int sp;
+    const u8* im = level_ptr(g, l0, l0pitch, pyr, frame, t.level, &sp);
+    u8* dst = blr + (size_t)frame * g.pyrFrameBytes + L.off;
+    const int w = L.w, h = L.h, dp = L.pitch, xg = t.x0, x0 = xg + 32 * cb;
+    const bool live = x0 < w;                                           // wave-uniform: a block past the right edge only helps loading
+    const int r = lane & 31, hh = lane >> 5;
+    b3_i32x4 th[2];
+    {
+        const int e = live ? t.th + cb : t.th;
+        const uint4 u0 = thTab[(size_t)e * 128 + lane], u1 = thTab[(size_t)e * 128 + 64 + lane];
+        th[0][0] = (int)u0.x; th[0][1] = (int)u0.y; th[0][2] = (int)u0.z; th[0][3] = (int)u0.w;
+        th[1][0] = (int)u1.x; th[1][1] = (int)u1.y; th[1][2] = (int)u1.z; th[1][3] = (int)u1.w;
+    }
+    const u32 selT1 = (r & 1) ? 0x03070105u : 0x06020400u;            // 4x4 byte transpose across a lane quad, stage 1 / 2
+    const u32 selT2 = (r & 2) ? 0x03020706u : 0x05040100u;
+    // staging: 32 source rows x 160 B (pixels xg - 16 .. xg + 143) per tile = 320 16-byte pieces; thread -> piece tid and
+    // piece min(256 + tid, 319) (only the first 64 threads park the second one).  Every load is unconditional on a clamped
+    // row / column -- a piece outside the image only ever meets zero weights, so any real pixels will do -- which keeps
+    // branches (and the compiler's conservative vmcnt waits) out of the loop.
+    const int it1 = min(256 + tid, 319);
+    const int pr0 = tid / 10, ps0 = tid - pr0 * 10, pr1 = it1 / 10, ps1 = it1 - pr1 * 10;
+    const int px0 = xg - 16 + 16 * ps0, px1 = xg - 16 + 16 * ps1;
+    const int pxc0 = (px0 >= 0 && px0 < sp) ? px0 : 0, pxc1 = (px1 >= 0 && px1 < sp) ? px1 : 0;
+    const int ldsW0 = pr0 * B3_LROW + 16 * ps0, ldsW1 = pr1 * B3_LROW + 16 * ps1;
+    const int ldsR = r * B3_LROW + 32 * cb + 16 * hh;
+    int yr0 = t.t0 * B3_ROWS - 3 + pr0, yr1 = t.t0 * B3_ROWS - 3 + pr1;          // source rows of this thread's pieces
+    u32 tvo = (u32)(t.tv * 1024 + lane * 16);
+    uint4 n0, n1;
+    auto fetch = [&]() {
+        n0 = gload128u(im, (u32)(__mul24(min(max(yr0, 0), h - 1), sp) + pxc0));
+        n1 = gload128u(im, (u32)(__mul24(min(max(yr1, 0), h - 1), sp) + pxc1));
+        yr0 += B3_ROWS; yr1 += B3_ROWS;
+    };
+    auto park = [&](int buf) {
+        const u32 m = 0x80808080u;
+        *(uint4*)(xs[buf] + ldsW0) = make_uint4(n0.x ^ m, n0.y ^ m, n0.z ^ m, n0.w ^ m);
+        if (tid < 64) *(uint4*)(xs[buf] + ldsW1) = make_uint4(n1.x ^ m, n1.y ^ m, n1.z ^ m, n1.w ^ m);
+    };
+    // memory operations retire in order and the compiler cannot count this kernel's predicated stores: per tile the order is
+    // [next Tv, next pixels] ... park (waits for both, nothing younger outstanding) ... stores, so the only wait of the loop
+    // is the one before parking and it never includes a store of the same tile
+    uint4 tvq = gload128u(tvTab, tvo), tvn = tvq;
+    fetch();
+    park(0);
+    __syncthreads();
+    b3_i32x16 c1, c2;                                                              // accumulator start values, kept in registers
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { c1[i] = 32768; c2[i] = 256 * 32768 + 32768 + 32768; }
+    const int q = r & 3;
+    const int obW = (q + 4 * hh) * B3_OROW + 32 * cb + (r & ~3);                   // this lane's dword of tile row q + 4hh (+ 8e rows)
+    // write-out: the workgroup's 26 x 128 px tile leaves as 16-byte pieces, 8 per row: full 128-byte lines per row
+    const int orow = tid >> 3, oseg = tid & 7;
+    const bool ocol = xg + 16 * oseg < w && orow < B3_ROWS;
+    const int obR = orow * B3_OROW + 16 * oseg;
+    int hrem = h - t.t0 * B3_ROWS - orow;                                          // > 0: this thread's output row is inside the image
+    u32 so = (u32)((t.t0 * B3_ROWS + orow) * dp + xg + 16 * oseg);
+    const u32 sstep = (u32)(B3_ROWS * dp);
+    for (int k = 0; k < t.nt; ++k) {
+        const int buf = k & 1;
+        const bool more = k + 1 < t.nt;
+        if (more) {                                                     // in flight while this tile is computed
+            tvo += 1024u;
+            tvn = gload128u(tvTab, tvo);
+            fetch();
+        }
+        b3_i32x16 aH, aL;
+        if (live) {
+            const uint4 a0 = *(const uint4*)(xs[buf] + ldsR);
+            const uint4 a1 = *(const uint4*)(xs[buf] + ldsR + 32);
+            b3_i32x4 A0, A1;
+            A0[0] = (int)a0.x; A0[1] = (int)a0.y; A0[2] = (int)a0.z; A0[3] = (int)a0.w;
+            A1[0] = (int)a1.x; A1[1] = (int)a1.y; A1[2] = (int)a1.z; A1[3] = (int)a1.w;
+            b3_i32x16 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, th[0], c1, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, th[1], acc, 0, 0, 0);
+            // ---- H (16-bit, one column per lane, 16 rows in the registers) -> low / high byte fragments
+            b3_i32x4 blo, bhi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const u32 p01 = __builtin_amdgcn_perm((u32)acc[4 * e + 1], (u32)acc[4 * e], 0x05010400u);       // r0.b0 r1.b0 r0.b1 r1.b1
+                const u32 p23 = __builtin_amdgcn_perm((u32)acc[4 * e + 3], (u32)acc[4 * e + 2], 0x05010400u);
+                blo[e] = (int)(__builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u);
+                bhi[e] = (int)(__builtin_amdgcn_perm(p23, p01, 0x07060302u) ^ 0x80808080u);
+            }
+            b3_i32x4 tv;
+            tv[0] = (int)tvq.x; tv[1] = (int)tvq.y; tv[2] = (int)tvq.z; tv[3] = (int)tvq.w;
+            aH = __builtin_amdgcn_mfma_i32_32x32x32_i8(tv, bhi, (b3_i32x16)(0), 0, 0, 0);
+            aL = __builtin_amdgcn_mfma_i32_32x32x32_i8(tv, blo, c2, 0, 0, 0);
+        }
+        if (live) {
+            // ---- lane = column x0 + r, register i = output row (i&3) + 8 (i>>2) + 4 hh of the tile, value in bits 16..23.
+            // Gather 4 rows per lane (3 v_perm), transpose the 4x4 bytes of each lane quad (2 quad_perm DPP moves + 2 v_perm):
+            // lane q of a quad then holds row q + 8e + 4hh of its 4 columns as one dword, which goes to the workgroup's output
+            // tile in LDS (double-buffered; the barrier below is the loop's only one) and leaves as full 128-byte rows.  (Byte
+            // stores crawl at a lane per clock, and dword stores straight from this layout write 32-byte runs: 0.55 ms.)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u32 R[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) R[b] = (u32)((aH[4 * e + b] << 8) + aL[4 * e + b]);
+                const u32 p01 = __builtin_amdgcn_perm(R[1], R[0], 0x0c0c0602u);             // R0.b2 R1.b2 0 0
+                const u32 p23 = __builtin_amdgcn_perm(R[3], R[2], 0x0c0c0602u);
+                u32 D = __builtin_amdgcn_perm(p23, p01, 0x05040100u);                      // rows 4e..4e+3 of this lane's column
+                u32 O = (u32)__builtin_amdgcn_mov_dpp((int)D, 0xB1, 0xf, 0xf, true);       // quad_perm [1,0,3,2]
+                D = __builtin_amdgcn_perm(O, D, selT1);
+                O = (u32)__builtin_amdgcn_mov_dpp((int)D, 0x4E, 0xf, 0xf, true);           // quad_perm [2,3,0,1]
+                D = __builtin_amdgcn_perm(O, D, selT2);                                    // row q + 8e + 4hh, columns xq..xq+3
+                *(u32*)(ob[buf] + obW + 8 * e * B3_OROW) = D;                              // row q + 4hh + 8e of the tile
+            }
+        }
+        // the next tile's pixels go to LDS before this tile's stores are issued: the wait for them then never includes a store
+        if (more) { park(buf ^ 1); tvq = tvn; }                         // (Tv was requested before the pixels: it has landed too)
+        // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the stores and the prefetch
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (ocol && hrem > 0) {
+            const uint4 v = *(const uint4*)(ob[buf] + obR);
+            *(__attribute__((address_space(1))) uint4*)((__attribute__((address_space(1))) u8*)dst + so) = v;
+        }
+        hrem -= B3_ROWS; so += sstep;
+    }
+#endif
+}
+
 #define BL_R 32
 struct BlurTask { short level, g0, y0, pad; };            // g0 = first dword column of the strip, y0 = first output row
 

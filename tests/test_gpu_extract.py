@@ -45,6 +45,14 @@ def test_extract_bit_exact(pkg, oracle, synth, w, h, nf, seed, lap, kind):
         assert n >= nf // 2
 
 
+@pytest.mark.parametrize("w,h,nf,seed,lap,kind", [CASES[0], CASES[2], CASES[6], (1920, 1080, 2000, 77, (0, 0), "textured")])
+def test_matrix_core_blur_bit_exact(pkg, oracle, synth, monkeypatch, w, h, nf, seed, lap, kind):
+    # ORBX_BLUR_MFMA: the 7x7 blur as two int8 Toeplitz products on the matrix cores (k_blur3) instead of the VALU kernel;
+    # every blurred level and the descriptors must still equal the oracle's (odd sizes: ragged strips, tiles and folds)
+    monkeypatch.setenv("ORBX_BLUR_MFMA", "1")
+    _check(pkg, oracle, synth, w, h, nf, seed, lap, kind)
+
+
 def test_extract_full_hd_4000(pkg, oracle, synth):
     # BASELINE config C5 at full size
     assert _check(pkg, oracle, synth, 1920, 1080, 4000, 300, (0, 0), "textured", stages=False) >= 3900
