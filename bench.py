@@ -240,14 +240,15 @@ def main():
         except Exception:
             copy_gbs = None
         out = {
-            "metric": "ORB extract+match frames/sec @752x480, 1000 feat",
+            "metric": "ORB extract+match frames/sec @%dx%d, %d feat" % (W, H, args.nfeatures),
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: %dx%d grayscale, %d features, 8 levels, scale 1.2, FAST 20/7; "
+            "config": {"workload": ("configs[1]: " if (W, H, args.nfeatures) == (752, 480, 1000) else "other size (not the headline config): ") +
+                                   "%dx%d grayscale, %d features, 8 levels, scale 1.2, FAST 20/7; "
                                    "batch of %d frames/GPU/step resident in HBM; extract + %s against the previous frame"
                                    % (W, H, args.nfeatures, B, "Frame grid build and SearchByProjection window match (th=15) of every keypoint"
-                                      if args.match == "window" else "dense 2-NN Hamming match"),
+                                      if args.match == "window" else "dense 2-NN Hamming match (int8 MFMA)"),
                        "frames_per_step_per_gpu": B, "handles_in_flight": NH, "keypoints_last_batch": int(total_kp.item())},
             "roofline": {"bound": "hbm", "kernel": "pyramid+FAST pass (k_resize2 x7 on stream 2 + k_fast3 x3 and k_fast_fix on stream 1; wall span by HIP events)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
