@@ -113,13 +113,15 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int
 //   ham(q, t) = popc(q) + sum_k t_k * (1 - 2 q_k)            (t_k, q_k the descriptor bits)
 // so with train bits as 0/1 bytes in the A operand and query bits as +-1 bytes in the B operand, v_mfma_i32_32x32x32_i8
 // accumulates ham - popc(q) for 32 train rows x 32 query columns; popc(q) is constant per column and is added at the end.
-// Bit -> byte expansion is one v_and per operand dword: dword e of a lane's fragment = (w >> 4h) & (0x01010101 << e), i.e.
-// bytes worth 0 or 2^e, and the query side carries the matching +-2^(3-e), so every product is +-8 and the accumulator
-// is 8 * (ham - popc(q)).  Which k each (lane half h, byte) lands on does not matter: A and B use the same map.
+// Bit -> byte expansion is one v_and per operand dword: a word is rotated once so that bits 4h + e + 8i sit at 3 + e + 8i, and
+// dword e of the fragment = rotated & (0x08080808 << e), i.e. bytes worth 0 or 2^(3+e); the query side carries the matching
+// +-2^(6-e), so every product is +-512 and the accumulator is 512 * (ham - popc(q)).  Which k each (lane half h, byte) lands on
+// does not matter: A and B use the same map.
 // Selection without leaving the accumulator layout (column = lane & 31 = query, 16 train rows per lane): the accumulator
-// starts at C = (row << 13) + 2048, so rotating the result right by 13 gives the packed key (8*ham' + 2048) << 19 | row,
-// whose unsigned order is (distance, train index) -- the reference's tie rule -- and one v_min + one v_med3 keep the two
-// smallest.  Rows are tile-relative: tiles are walked from the last to the first and the kept keys move up by 32 per tile.
+// starts at C = 2^17 + row, so the result IS a packed key (ham' + 256) << 9 | row whose unsigned order is (distance, train
+// index) -- the reference's tie rule -- and one v_min + one v_med3 per distance keep the two smallest: no per-distance op
+// besides those two.  Rows are tile-relative: tiles are walked from the last to the first and the kept keys move up by 32 per
+// tile; the 9-bit row field holds 16 tiles, after which the two keys are widened to (distance + 256) << 19 | absolute index.
 // A wave owns 64 queries (two B fragments sets) and streams the pair's train descriptors from L2; no LDS, no barrier.
 // Limits (host-checked): t_stride <= KM_MAX_NT.
 // ------------------------------------------------------------------------------------------------
@@ -137,8 +139,7 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t* __restrict__ q
     const int q0 = blockIdx.x * 256 + wv * 64;
     if (q0 >= nQ) return;                                     // wave-uniform; the kernel has no barrier
     const int r = lane & 31, h = lane >> 5;
-    const unsigned SENT = 0xFFF80000u;                        // distance field all ones: "no neighbour"
-    // ---- query side: +-2^(3-e) bytes, built once
+    // ---- query side: +-2^(6-e) bytes, built once
     km_i32x4 bf[2][8];
     int pq[2];
 #pragma unroll
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t* __restrict__ q
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const unsigned y = (wp >> e) & 0x01010101u;              // the bit, per byte
-                const unsigned mag = 8u >> e;
+                const unsigned mag = 64u >> e;
                 bf[n][s][e] = (int)(mag * 0x01010101u + y * (256u - 2u * mag));   // bit ? -mag : +mag as int8 (no carries: <= 255 per byte)
             }
         }
@@ -166,8 +167,11 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t* __restrict__ q
     }
     km_i32x16 cin;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) cin[i] = ((((i & 3) + 8 * (i >> 2) + 4 * h)) << 13) + 2048;
-    unsigned k0[2] = {SENT, SENT}, k1[2] = {SENT, SENT};
+    for (int i = 0; i < 16; ++i) cin[i] = (1 << 17) + (i & 3) + 8 * (i >> 2) + 4 * h;
+    const unsigned SENT = 0x7FFFFE00u;                        // window key "no neighbour" (survives 16 x += 32)
+    unsigned k0[2] = {SENT, SENT}, k1[2] = {SENT, SENT};      // two smallest window keys per query set
+    unsigned G0[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, G1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};   // two smallest (distance+256) << 19 | train index
+    const int rot = h ? 1 : 29;                               // rotate right: bits 4h + e + 8i of a word -> positions 3 + e + 8i
     const uint8_t* tb = t + (size_t)pair * t_stride * 32;
     const int ntile = (nT + 31) >> 5;
     uint4 nlo = make_uint4(0, 0, 0, 0), nhi = nlo;
@@ -185,9 +189,9 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t* __restrict__ q
         km_i32x16 acc0 = cin, acc1 = cin;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const unsigned wp = w[s] >> (4 * h);
+            const unsigned wp = __builtin_amdgcn_alignbit(w[s], w[s], rot);
             km_i32x4 a;
-            a[0] = (int)(wp & 0x01010101u); a[1] = (int)(wp & 0x02020202u); a[2] = (int)(wp & 0x04040404u); a[3] = (int)(wp & 0x08080808u);
+            a[0] = (int)(wp & 0x08080808u); a[1] = (int)(wp & 0x10101010u); a[2] = (int)(wp & 0x20202020u); a[3] = (int)(wp & 0x40404040u);
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[0][s], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[1][s], acc1, 0, 0, 0);
         }
@@ -195,38 +199,46 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t* __restrict__ q
         if (tile * 32 + 32 <= nT) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const unsigned ka = __builtin_amdgcn_alignbit((unsigned)acc0[i], (unsigned)acc0[i], 13);
-                const unsigned kb = __builtin_amdgcn_alignbit((unsigned)acc1[i], (unsigned)acc1[i], 13);
-                k1[0] = umed3(k0[0], k1[0], ka); k0[0] = min(k0[0], ka);
-                k1[1] = umed3(k0[1], k1[1], kb); k0[1] = min(k0[1], kb);
+                k1[0] = umed3(k0[0], k1[0], (unsigned)acc0[i]); k0[0] = min(k0[0], (unsigned)acc0[i]);
+                k1[1] = umed3(k0[1], k1[1], (unsigned)acc1[i]); k0[1] = min(k0[1], (unsigned)acc1[i]);
             }
         } else {                                              // the ragged last tile: rows past nT are not candidates
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const bool ok = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h < nT;
-                const unsigned ka = ok ? __builtin_amdgcn_alignbit((unsigned)acc0[i], (unsigned)acc0[i], 13) : SENT;
-                const unsigned kb = ok ? __builtin_amdgcn_alignbit((unsigned)acc1[i], (unsigned)acc1[i], 13) : SENT;
+                const unsigned ka = ok ? (unsigned)acc0[i] : SENT, kb = ok ? (unsigned)acc1[i] : SENT;
                 k1[0] = umed3(k0[0], k1[0], ka); k0[0] = min(k0[0], ka);
                 k1[1] = umed3(k0[1], k1[1], kb); k0[1] = min(k0[1], kb);
+            }
+        }
+        if ((tile & 15) == 0) {                               // window done: widen its two keys to absolute train indices
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const unsigned base = (unsigned)tile * 32u;
+                const unsigned g0 = k0[n] < 0x40000000u ? ((k0[n] >> 9) << 19) | (base + (k0[n] & 511u)) : 0xFFFFFFFFu;
+                const unsigned g1 = k1[n] < 0x40000000u ? ((k1[n] >> 9) << 19) | (base + (k1[n] & 511u)) : 0xFFFFFFFFu;
+                G1[n] = umed3(G0[n], G1[n], g0); G0[n] = min(G0[n], g0);
+                G1[n] = umed3(G0[n], G1[n], g1); G0[n] = min(G0[n], g1);
+                k0[n] = SENT; k1[n] = SENT;
             }
         }
     }
     // ---- the two lane halves saw disjoint train rows of the same query: merge, then half h stores query set h
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-        const unsigned o0 = (unsigned)__shfl_xor((int)k0[n], 32), o1 = (unsigned)__shfl_xor((int)k1[n], 32);
-        k1[n] = umed3(k0[n], k1[n], o0); k0[n] = min(k0[n], o0);
-        k1[n] = umed3(k0[n], k1[n], o1); k0[n] = min(k0[n], o1);
+        const unsigned o0 = (unsigned)__shfl_xor((int)G0[n], 32), o1 = (unsigned)__shfl_xor((int)G1[n], 32);
+        G1[n] = umed3(G0[n], G1[n], o0); G0[n] = min(G0[n], o0);
+        G1[n] = umed3(G0[n], G1[n], o1); G0[n] = min(G0[n], o1);
     }
-    const unsigned f0 = h ? k0[1] : k0[0], f1 = h ? k1[1] : k1[0];
+    const unsigned f0 = h ? G0[1] : G0[0], f1 = h ? G1[1] : G1[0];
     const int pqs = h ? pq[1] : pq[0];
     const int qi = q0 + h * 32 + r;
     if (qi < nQ) {
         const size_t o = ((size_t)pair * q_stride + qi) * 2;
-        const bool h0 = (f0 >> 19) != 0x1FFFu, h1 = (f1 >> 19) != 0x1FFFu;
+        const bool h0 = f0 != 0xFFFFFFFFu, h1 = f1 != 0xFFFFFFFFu;
         idx2[o] = h0 ? (int)(f0 & 0x7FFFFu) : -1; idx2[o + 1] = h1 ? (int)(f1 & 0x7FFFFu) : -1;
-        dist2[o] = h0 ? (((int)(f0 >> 19) - 2048) >> 3) + pqs : -1;
-        dist2[o + 1] = h1 ? (((int)(f1 >> 19) - 2048) >> 3) + pqs : -1;
+        dist2[o] = h0 ? (int)(f0 >> 19) - 256 + pqs : -1;
+        dist2[o + 1] = h1 ? (int)(f1 >> 19) - 256 + pqs : -1;
     }
 #endif
 }
