@@ -209,6 +209,12 @@ def main():
     if rank == 0:
         frames = B * args.steps * world
         alg, fused = ex.algorithmic_bytes()
+        # the blur's compulsory traffic is 2 * (sum of level pixels) = 2 * (alg - fused); it belongs to the pass
+        # when the blur is scheduled inside it (default: matrix-core blur behind the resize chain, beside FAST) -- the span
+        # then ends with the later of FAST and blur
+        blur_in = ex.blur_in_pass()
+        if blur_in:
+            alg = alg + 2 * (alg - fused)
         # every handle processes its share of the batch concurrently: per-launch-group figure = bytes of ONE handle's
         # frames / that handle's own pyramid+FAST wall span (conservative: the spans overlap other handles' kernels)
         pf_ms = float(np.mean(t_pyr) + np.mean(t_fast))
@@ -218,7 +224,7 @@ def main():
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             c = tj["config"]
             if (c["width"], c["height"], c["nfeatures"]) == (W, H, args.nfeatures):
-                traffic = tj["pyramid_fast_bytes_per_frame"] * (B / NH)
+                traffic = (tj["pyramid_fast_bytes_per_frame"] + (tj["blur_bytes_per_frame"] if blur_in else 0)) * (B / NH)
         except Exception:
             traffic = None
         stage = {k: float(np.mean([tm[k] for tm, _ in t_all])) for k in t_all[0][0]}
@@ -250,7 +256,8 @@ def main():
                                    % (W, H, args.nfeatures, B, "Frame grid build and SearchByProjection window match (th=15) of every keypoint"
                                       if args.match == "window" else "dense 2-NN Hamming match (int8 MFMA)"),
                        "frames_per_step_per_gpu": B, "handles_in_flight": NH, "keypoints_last_batch": int(total_kp.item())},
-            "roofline": {"bound": "hbm", "kernel": "pyramid+FAST pass (k_resize2 x7 on stream 2 + k_fast3 x3 and k_fast_fix on stream 1; wall span by HIP events)",
+            "roofline": {"bound": "hbm", "kernel": ("pyramid+FAST+blur pass (k_resize2 x7 then k_blur3 on stream 2 + k_fast3 x3 and k_fast_fix on stream 1; wall span by HIP events)"
+                                    if blur_in else "pyramid+FAST pass (k_resize2 x7 on stream 2 + k_fast3 x3 and k_fast_fix on stream 1; wall span by HIP events)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg * (B / NH), "frames_per_launch": B / NH, "algorithmic_bytes_per_frame": alg, "fused_lower_bound_per_frame": fused,
                          "launch_ms": pf_ms, "measured_copy_peak_GBps": copy_gbs,

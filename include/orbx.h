@@ -91,6 +91,10 @@ int orbx_level_selected(orbx_t*, int frame, int level, int32_t* xyr, int cap);
  * 5 orient+descriptor, 6 total, 7 wall span from the first resize/FAST launch to the end of the last FAST launch
  * (the two streams overlap, so 0+1 double-counts; 7 is the figure the roofline uses).  ms8 holds 8 floats. */
 int orbx_last_timings(orbx_t*, float* ms8);
+/* 1 when the Gaussian blur is scheduled inside that pass (the default: the matrix-core blur runs directly behind the resize
+ * chain, beside FAST): ms8[7] then ends with the later of FAST and blur, and the pass's algorithmic traffic includes the
+ * blur's read + write of every level (2 * sum of level pixels).  0 with ORBX_BLUR_V2 / ORBX_BLUR_LATE. */
+int orbx_blur_in_pass(const orbx_t*);
 /* stage-boundary events are optional: with `on` = 0 only the dependency events are recorded (a few microseconds less per
  * batch); orbx_last_timings / orbx_mean_timings then fill ms8[6] (total) and ms8[7] (pyramid+FAST span) and zero the rest.
  * Default on.  Restarts the timing ring. */

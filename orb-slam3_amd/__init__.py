@@ -27,7 +27,7 @@ EXPORTS = [
     "orbx_create", "orbx_destroy", "orbx_last_error", "orbx_max_keypoints", "orbx_extract", "orbx_extract_batch",
     "orbx_extract_batch_async", "orbx_sync", "orbx_result_device", "orbx_result_fetch", "orbx_result_fetch_all", "orbx_level_size",
     "orbx_level_image", "orbx_scale_tables", "orbx_features_per_level", "orbx_level_candidates",
-    "orbx_level_selected", "orbx_last_timings", "orbx_set_stage_timing", "orbx_mean_timings", "orbx_stream_wait_results", "orbx_stream_wait_other", "orbx_gray_from_color", "orbx_remap_linear", "orbx_clahe", "orbx_algorithmic_bytes", "orbx_stream", "orbx_dev_alloc",
+    "orbx_level_selected", "orbx_last_timings", "orbx_set_stage_timing", "orbx_mean_timings", "orbx_stream_wait_results", "orbx_stream_wait_other", "orbx_gray_from_color", "orbx_remap_linear", "orbx_clahe", "orbx_algorithmic_bytes", "orbx_blur_in_pass", "orbx_stream", "orbx_dev_alloc",
     "orbx_dev_free", "orbx_memcpy_h2d", "orbx_memcpy_d2h", "orbx_device_count",
     # include/orbm.h
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_sync", "orbm_stream", "orbm_set_stream", "orbm_hamming",
@@ -72,6 +72,7 @@ def lib():
         L.orbx_level_selected.argtypes = [vp, ci, ci, vp, ci]
         L.orbx_last_timings.argtypes = [vp, vp]
         L.orbx_algorithmic_bytes.restype = C.c_int64
+        L.orbx_blur_in_pass.argtypes = [vp]
         L.orbx_algorithmic_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
         L.orbx_mean_timings.argtypes = [vp, vp, i32p]
         L.orbx_stream_wait_results.argtypes = [vp, vp]
@@ -340,6 +341,10 @@ class ORBextractor:
         t = np.zeros(8, np.float32); n = C.c_int32()
         _chk(self.L.orbx_mean_timings(self.h, _p(t), C.byref(n)), "mean_timings")
         return dict(zip(["pyramid", "fast", "quadtree", "slots", "blur", "orient_desc", "total", "pyramid_fast_span"], t.tolist())), n.value
+
+    def blur_in_pass(self):
+        """True when the blur is scheduled inside the pyramid+FAST pass (include/orbx.h: orbx_blur_in_pass)."""
+        return bool(self.L.orbx_blur_in_pass(self.h))
 
     def algorithmic_bytes(self):
         f = C.c_int64()

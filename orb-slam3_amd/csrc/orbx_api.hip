@@ -62,7 +62,7 @@ struct orbx {
     int64_t algBytes = 0, fusedBytes = 0;
     size_t qtLds = 0, qt2Lds = 0;
     int qt2Cap = 0, qt2Sort = 0;
-    bool qtV1 = false, odV1 = false, serial = false, blurV2 = true;
+    bool qtV1 = false, odV1 = false, serial = false, blurV2 = false, blurEarly = true;
     bool qtWide = false;                                       // 1024-thread quadtree workgroups (large frames / feature counts)
     int qtWideForce = -1;                                      // ORBX_QT_WIDE=0/1: A/B switch
     // device
@@ -447,10 +447,14 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     o->maxW = max_w; o->maxH = max_h; o->maxBatch = max_batch;
     o->fastV1 = getenv("ORBX_FAST_V1") != nullptr;
     o->qtV1 = getenv("ORBX_QT_V1") != nullptr;
-    o->blurV2 = getenv("ORBX_BLUR_MFMA") == nullptr;         // default: the VALU blur (k_blur2); ORBX_BLUR_MFMA selects the matrix-core k_blur3 (A/B)
+    // default: the matrix-core blur (k_blur3) directly behind the resize chain, i.e. beside FAST (which is VALU/LDS-bound, while
+    // k_blur3 is memory + MFMA).  A/B switches: ORBX_BLUR_V2 = the VALU blur (k_blur2) beside the quadtree as before;
+    // ORBX_BLUR_LATE = k_blur3 but beside the quadtree.
+    o->blurV2 = getenv("ORBX_BLUR_V2") != nullptr;
     o->odV1 = getenv("ORBX_OD_V1") != nullptr;
     if (const char* e = getenv("ORBX_FAST_QCAP")) o->f3QcapForce = atoi(e);
     if (const char* e = getenv("ORBX_QT_WIDE")) o->qtWideForce = atoi(e) != 0 ? 1 : 0;
+    o->blurEarly = !o->blurV2 && getenv("ORBX_BLUR_LATE") == nullptr;
     o->serial = getenv("ORBX_SERIAL") != nullptr;            // A/B switch: simple per-cell reference kernel
     o->scaleFactor = scale_factor;                              // double member initialised from float (ORBextractor.h:96)
     const int L = nlevels;
@@ -640,7 +644,7 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     }
     HIPCHK(hipEventRecord(o->ev[2], st));
     // blur (VALU + HBM) runs beside the quadtree (LDS-latency bound), not beside FAST (VALU bound)
-    if (!o->serial) HIPCHK(hipStreamWaitEvent(s1, o->ev[2], 0));
+    if (!o->serial && !o->blurEarly) HIPCHK(hipStreamWaitEvent(s1, o->ev[2], 0));
     STAGE_EV(11, s1);
     if (o->blurV2)
         hipLaunchKernelGGL(k_blur2, dim3((unsigned)(o->tiles.size() + 3) / 4, nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
@@ -852,6 +856,11 @@ static int timings_of(orbx* o, hipEvent_t* ev, float* ms7) {
         for (int i = 0; i < 6; ++i) ms7[i] = 0.f;
         HIPCHK(hipEventElapsedTime(&ms7[6], ev[0], ev[6]));
         HIPCHK(hipEventElapsedTime(&ms7[7], ev[0], ev[2]));
+        if (o->blurEarly && !o->serial) {
+            float b = 0;
+            HIPCHK(hipEventElapsedTime(&b, ev[0], ev[9]));
+            ms7[7] = std::max(ms7[7], b);
+        }
         return ORBX_OK;
     }
     HIPCHK(hipEventElapsedTime(&ms7[0], ev[7], ev[8]));      // resize chain (stream 2)
@@ -864,6 +873,11 @@ static int timings_of(orbx* o, hipEvent_t* ev, float* ms7) {
     HIPCHK(hipEventElapsedTime(&ms7[5], ev[5], ev[6]));
     HIPCHK(hipEventElapsedTime(&ms7[6], ev[0], ev[6]));
     HIPCHK(hipEventElapsedTime(&ms7[7], ev[0], ev[2]));      // wall span of the pyramid+FAST pass (both streams)
+    if (o->blurEarly && !o->serial) {                        // the blur runs inside the pass: it ends with the later of FAST and blur
+        float b = 0;
+        HIPCHK(hipEventElapsedTime(&b, ev[0], ev[9]));
+        ms7[7] = std::max(ms7[7], b);
+    }
     return ORBX_OK;
 }
 
@@ -892,6 +906,8 @@ int orbx_mean_timings(orbx_t* o, float* ms8, int* nsamples) {
     if (nsamples) *nsamples = n;
     return ORBX_OK;
 }
+
+int orbx_blur_in_pass(const orbx_t* o) { return o && o->blurEarly && !o->serial ? 1 : 0; }
 
 int orbx_set_stage_timing(orbx_t* o, int on) {
     if (!o) return ORBX_E_INVALID;

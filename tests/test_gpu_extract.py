@@ -45,12 +45,23 @@ def test_extract_bit_exact(pkg, oracle, synth, w, h, nf, seed, lap, kind):
         assert n >= nf // 2
 
 
-@pytest.mark.parametrize("w,h,nf,seed,lap,kind", [CASES[0], CASES[2], CASES[6], (1920, 1080, 2000, 77, (0, 0), "textured")])
-def test_matrix_core_blur_bit_exact(pkg, oracle, synth, monkeypatch, w, h, nf, seed, lap, kind):
-    # ORBX_BLUR_MFMA: the 7x7 blur as two int8 Toeplitz products on the matrix cores (k_blur3) instead of the VALU kernel;
-    # every blurred level and the descriptors must still equal the oracle's (odd sizes: ragged strips, tiles and folds)
-    monkeypatch.setenv("ORBX_BLUR_MFMA", "1")
+@pytest.mark.parametrize("switch", ["ORBX_BLUR_V2", "ORBX_BLUR_LATE"])
+@pytest.mark.parametrize("w,h,nf,seed,lap,kind", [CASES[0], CASES[6], (1920, 1080, 2000, 77, (0, 0), "textured")])
+def test_blur_variants_bit_exact(pkg, oracle, synth, monkeypatch, switch, w, h, nf, seed, lap, kind):
+    # default: the 7x7 blur as two int8 Toeplitz products on the matrix cores (k_blur3) scheduled beside FAST -- covered by
+    # every other test here.  ORBX_BLUR_V2 = the VALU kernel (k_blur2) beside the quadtree, ORBX_BLUR_LATE = k_blur3 beside the
+    # quadtree: every blurred level and the descriptors must equal the oracle's either way (odd sizes: ragged strips and folds)
+    monkeypatch.setenv(switch, "1")
+    ex = pkg.ORBextractor(100, max_size=(w, h), max_batch=1)
+    assert not ex.blur_in_pass()
+    ex.close()
     _check(pkg, oracle, synth, w, h, nf, seed, lap, kind)
+
+
+def test_blur_is_inside_the_pass_by_default(pkg):
+    ex = pkg.ORBextractor(100, max_size=(752, 480), max_batch=1)
+    assert ex.blur_in_pass()
+    ex.close()
 
 
 def test_extract_full_hd_4000(pkg, oracle, synth):

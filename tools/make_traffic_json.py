@@ -25,11 +25,15 @@ steps = len(F["k_resize2"]) / 7.0          # seven resize launches per step (lev
 fast_fetch = (sum(F["k_fast3"]) + sum(F.get("k_fast_fix", [0]))) / steps; rz_fetch = (sum(F["k_resize2"]) + sum(F.get("k_resize", [0]))) / steps
 fast_write = (sum(W["k_fast3"]) + sum(W.get("k_fast_fix", [0]))) / steps; rz_write = (sum(W["k_resize2"]) + sum(W.get("k_resize", [0]))) / steps
 traffic = (2.0 * fast_fetch + rz_fetch + fast_write + rz_write) * 1024 / B
+bl_fetch = sum(F.get("k_blur3", [0])) / steps; bl_write = sum(W.get("k_blur3", [0])) / steps     # 16 B/lane loads: doubled like k_fast3
+blur_traffic = (2.0 * bl_fetch + bl_write) * 1024 / B
 out = {"config": {"width": 752, "height": 480, "nfeatures": 1000, "batch": B},
        "units": "bytes per frame for the pyramid+FAST pass (k_resize2 x7 + k_fast3 x3 + k_fast_fix), rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes (KB)",
-       "raw_kb_per_step": {"k_fast3_fetch": fast_fetch, "k_resize_fetch": rz_fetch, "k_fast3_write": fast_write, "k_resize_write": rz_write},
+       "raw_kb_per_step": {"k_fast3_fetch": fast_fetch, "k_resize_fetch": rz_fetch, "k_fast3_write": fast_write, "k_resize_write": rz_write,
+                           "k_blur3_fetch": bl_fetch, "k_blur3_write": bl_write},
        "correction": "k_fast3 loads 16 B/lane: FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); k_resize2 loads 4 B/lane: uncalibrated, as is; WRITE_SIZE exact",
-       "pyramid_fast_bytes_per_frame": traffic, "algorithmic_bytes_per_frame": 2963001}
+       "pyramid_fast_bytes_per_frame": traffic, "algorithmic_bytes_per_frame": 2963001,
+       "blur_bytes_per_frame": blur_traffic, "blur_algorithmic_bytes_per_frame": 2234734}
 json.dump(out, open(os.path.join(ROOT, "profiles", "r01_traffic.json"), "w"), indent=1)
 shutil.copy(ff, os.path.join(ROOT, "profiles", "r01_pmc_fetch_counter_collection.csv"))
 shutil.copy(wf, os.path.join(ROOT, "profiles", "r01_pmc_write_counter_collection.csv"))
