@@ -213,6 +213,7 @@ def main():
         # when the blur is scheduled inside it (default: matrix-core blur behind the resize chain, beside FAST) -- the span
         # then ends with the later of FAST and blur
         blur_in = ex.blur_in_pass()
+        alg_pf = alg
         if blur_in:
             alg = alg + 2 * (alg - fused)
         # every handle processes its share of the batch concurrently: per-launch-group figure = bytes of ONE handle's
@@ -261,6 +262,12 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg * (B / NH), "frames_per_launch": B / NH, "algorithmic_bytes_per_frame": alg, "fused_lower_bound_per_frame": fused,
                          "launch_ms": pf_ms, "measured_copy_peak_GBps": copy_gbs,
+                         # for continuity with the pyramid+FAST-only figure: its own bytes over the span to the end of the last FAST
+                         # launch (stage events of the untimed staged pass; FAST is stretched by the blur running beside it)
+                         "pyramid_fast_only": ({"algorithmic_bytes_per_frame": alg_pf, "span_ms": stage["fast"],
+                                                "achieved": alg_pf * (B / NH) / (stage["fast"] * 1e-3) / 1e9,
+                                                "frac": alg_pf * (B / NH) / (stage["fast"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                               if blur_in and stage.get("fast", 0) > 0 else None),
                          "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None},
             "stage_ms_per_step": stage,
         }

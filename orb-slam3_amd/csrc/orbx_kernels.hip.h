@@ -1233,9 +1233,9 @@ __device__ __forceinline__ int reflect101(int p, int n) {   // valid for -n < p 
 // k_blur3: the same blur on the matrix cores.  Both passes are small integer matrix products with banded (Toeplitz)
 // weight matrices, and the arithmetic is exact in int8 x int8 -> int32:
 //   pass 1   H[32 rows][32 cols] = X[32 rows][64 px] . Th[64 px][32 cols]      (2 x v_mfma_i32_32x32x32_i8)
-//            X as (pixel - 128): one 16-byte row load + 4 v_xor per lane and k-step; Th[p][c] = sum of the taps whose
-//            reflect-101 source pixel for output column c is p (7 taps, sum 256), so the accumulator started at 32768 holds
-//            the reference's Q8.8 row sum (<= 65280) exactly, borders included.
+//            X as (pixel - 128); Th[p][c] = sum of the taps whose reflect-101 source pixel for output column c is p (7 taps,
+//            sum 256), so the accumulator holds the reference's Q8.8 row sum (<= 65280) minus 32768 exactly, borders
+//            included: a signed 16-bit number.
 //   pass 2   V = Tv[32 out rows][32 H rows] . H   with H split into its low and high bytes (2 MFMAs): the accumulator tile
 //            of pass 1 (column on the lane, 16 rows in the registers) IS the B operand layout of a product that sums over
 //            its rows -- 4 v_perm gather the bytes of 4 registers, no lane movement, no LDS; Tv carries the k order of the
@@ -1250,7 +1250,9 @@ __device__ __forceinline__ int reflect101(int p, int n) {   // valid for -n < p 
 // geometry is built (built in the kernel they cost more than the tiles themselves); border folds are just table entries.
 // ------------------------------------------------------------------------------------------------
 #define B3_ROWS 26
-#define B3_CHUNK 4
+#ifndef B3_CHUNK
+#define B3_CHUNK 8
+#endif
 struct Blur3Task { short level, x0, t0, nt; int th, tv; };   // th / tv: entries of the weight tables (tv: of tile t0)
 typedef int b3_i32x4 __attribute__((ext_vector_type(4)));
 typedef int b3_i32x16 __attribute__((ext_vector_type(16)));
@@ -1359,9 +1361,9 @@ __global__ __launch_bounds__(256) void k_blur3(Geom g, const u8* const* l0, int 
     fetch();
     park(0);
     __syncthreads();
-    b3_i32x16 c1, c2;                                                              // accumulator start values, kept in registers
+    b3_i32x16 c2;                                                                  // pass-2 start value: offsets of both passes + rounding
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { c1[i] = 32768; c2[i] = 256 * 32768 + 32768 + 32768; }
+    for (int i = 0; i < 16; ++i) c2[i] = 256 * 32768 + 32768 + 32768;
     const int q = r & 3;
     const int obW = (q + 4 * hh) * B3_OROW + 32 * cb + (r & ~3);                   // this lane's dword of tile row q + 4hh (+ 8e rows)
     // write-out: the workgroup's 26 x 128 px tile leaves as 16-byte pieces, 8 per row: full 128-byte lines per row
@@ -1386,16 +1388,17 @@ __global__ __launch_bounds__(256) void k_blur3(Geom g, const u8* const* l0, int 
             b3_i32x4 A0, A1;
             A0[0] = (int)a0.x; A0[1] = (int)a0.y; A0[2] = (int)a0.z; A0[3] = (int)a0.w;
             A1[0] = (int)a1.x; A1[1] = (int)a1.y; A1[2] = (int)a1.z; A1[3] = (int)a1.w;
-            b3_i32x16 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, th[0], c1, 0, 0, 0);
+            b3_i32x16 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, th[0], (b3_i32x16)(0), 0, 0, 0);   // H - 32768: signed 16-bit
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, th[1], acc, 0, 0, 0);
-            // ---- H (16-bit, one column per lane, 16 rows in the registers) -> low / high byte fragments
+            // ---- H - 32768 (signed 16-bit, one column per lane, 16 rows in the registers) -> low / high byte fragments: the
+            // high byte is a signed int8 as it stands, the low byte becomes one by - 128 (the 128s are part of c2)
             b3_i32x4 blo, bhi;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const u32 p01 = __builtin_amdgcn_perm((u32)acc[4 * e + 1], (u32)acc[4 * e], 0x05010400u);       // r0.b0 r1.b0 r0.b1 r1.b1
                 const u32 p23 = __builtin_amdgcn_perm((u32)acc[4 * e + 3], (u32)acc[4 * e + 2], 0x05010400u);
                 blo[e] = (int)(__builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u);
-                bhi[e] = (int)(__builtin_amdgcn_perm(p23, p01, 0x07060302u) ^ 0x80808080u);
+                bhi[e] = (int)__builtin_amdgcn_perm(p23, p01, 0x07060302u);
             }
             b3_i32x4 tv;
             tv[0] = (int)tvq.x; tv[1] = (int)tvq.y; tv[2] = (int)tvq.z; tv[3] = (int)tvq.w;
