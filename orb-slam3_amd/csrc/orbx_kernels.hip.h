@@ -1329,8 +1329,6 @@ __global__ __launch_bounds__(256) void k_blur3(Geom g, const u8* const* l0, int 
         th[0][0] = (int)u0.x; th[0][1] = (int)u0.y; th[0][2] = (int)u0.z; th[0][3] = (int)u0.w;
         th[1][0] = (int)u1.x; th[1][1] = (int)u1.y; th[1][2] = (int)u1.z; th[1][3] = (int)u1.w;
     }
-    const u32 selT1 = (r & 1) ? 0x03070105u : 0x06020400u;            // 4x4 byte transpose across a lane quad, stage 1 / 2
-    const u32 selT2 = (r & 2) ? 0x03020706u : 0x05040100u;
     // staging: 32 source rows x 160 B (pixels xg - 16 .. xg + 143) per tile = 320 16-byte pieces; thread -> piece tid and
     // piece min(256 + tid, 319) (only the first 64 threads park the second one).  Every load is unconditional on a clamped
     // row / column -- a piece outside the image only ever meets zero weights, so any real pixels will do -- which keeps
@@ -1364,8 +1362,6 @@ __global__ __launch_bounds__(256) void k_blur3(Geom g, const u8* const* l0, int 
     b3_i32x16 c2;                                                                  // pass-2 start value: offsets of both passes + rounding
 #pragma unroll
     for (int i = 0; i < 16; ++i) c2[i] = 256 * 32768 + 32768 + 32768;
-    const int q = r & 3;
-    const int obW = (q + 4 * hh) * B3_OROW + 32 * cb + (r & ~3);                   // this lane's dword of tile row q + 4hh (+ 8e rows)
     // write-out: the workgroup's 26 x 128 px tile leaves as 16-byte pieces, 8 per row: full 128-byte lines per row
     const int orow = tid >> 3, oseg = tid & 7;
     const bool ocol = xg + 16 * oseg < w && orow < B3_ROWS;
@@ -1406,24 +1402,16 @@ __global__ __launch_bounds__(256) void k_blur3(Geom g, const u8* const* l0, int 
             aL = __builtin_amdgcn_mfma_i32_32x32x32_i8(tv, blo, c2, 0, 0, 0);
         }
         if (live) {
-            // ---- lane = column x0 + r, register i = output row (i&3) + 8 (i>>2) + 4 hh of the tile, value in bits 16..23.
-            // Gather 4 rows per lane (3 v_perm), transpose the 4x4 bytes of each lane quad (2 quad_perm DPP moves + 2 v_perm):
-            // lane q of a quad then holds row q + 8e + 4hh of its 4 columns as one dword, which goes to the workgroup's output
-            // tile in LDS (double-buffered; the barrier below is the loop's only one) and leaves as full 128-byte rows.  (Byte
-            // stores crawl at a lane per clock, and dword stores straight from this layout write 32-byte runs: 0.55 ms.)
+            // ---- lane = column x0 + r, register i = output row (i&3) + 8 (i>>2) + 4 hh of the tile, value in bits 16..23: one LDS
+            // byte write each into the workgroup's output tile (double-buffered; the barrier below is the loop's only one), which
+            // then leaves as full 128-byte rows.  (Global byte stores crawl at a lane per clock, dword stores straight from this
+            // layout write 32-byte runs: 0.55 ms; a 4x4 byte transpose across lane quads -- 3 v_perm + 2 DPP moves + 2 v_perm per
+            // four rows -- ahead of dword LDS writes costs 28 VALU per tile more than these 16 LDS writes and the pass is
+            // VALU-bound.)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                u32 R[4];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) R[b] = (u32)((aH[4 * e + b] << 8) + aL[4 * e + b]);
-                const u32 p01 = __builtin_amdgcn_perm(R[1], R[0], 0x0c0c0602u);             // R0.b2 R1.b2 0 0
-                const u32 p23 = __builtin_amdgcn_perm(R[3], R[2], 0x0c0c0602u);
-                u32 D = __builtin_amdgcn_perm(p23, p01, 0x05040100u);                      // rows 4e..4e+3 of this lane's column
-                u32 O = (u32)__builtin_amdgcn_mov_dpp((int)D, 0xB1, 0xf, 0xf, true);       // quad_perm [1,0,3,2]
-                D = __builtin_amdgcn_perm(O, D, selT1);
-                O = (u32)__builtin_amdgcn_mov_dpp((int)D, 0x4E, 0xf, 0xf, true);           // quad_perm [2,3,0,1]
-                D = __builtin_amdgcn_perm(O, D, selT2);                                    // row q + 8e + 4hh, columns xq..xq+3
-                *(u32*)(ob[buf] + obW + 8 * e * B3_OROW) = D;                              // row q + 4hh + 8e of the tile
+            for (int i = 0; i < 16; ++i) {
+                const u32 R = (u32)((aH[i] << 8) + aL[i]);
+                ob[buf][((i & 3) + 8 * (i >> 2) + 4 * hh) * B3_OROW + 32 * cb + r] = (u8)(R >> 16);   // ds_write_b8_d16_hi
             }
         }
         // the next tile's pixels go to LDS before this tile's stores are issued: the wait for them then never includes a store
