@@ -42,7 +42,8 @@ struct orbx {
     Geom g;
     std::vector<CellInfo> cells;
     std::vector<BlurTask> tiles;
-    std::vector<Blur3Task> tiles3;                            // k_blur3 (matrix-core blur) tasks
+    std::vector<Blur3Task> tiles3;                            // k_blur3 (matrix-core blur) tasks: B3_CHUNK-tile walks, then one-tile tasks
+    size_t nTiles3Walk = 0;                                   // (small batches take the one-tile list: more, shorter workgroups)
     std::vector<u32> b3Th, b3Tv;                              // its weight fragments: [strip][2][64][4], [tile row][64][4]
     BlurSel blurSel;
     std::vector<StripInfo> strips;
@@ -119,6 +120,7 @@ static int build_geometry(orbx* o, int w, int h) {
     memset(&g, 0, sizeof g);
     const int L = o->nlevels;
     g.nlevels = L; g.w0 = w; g.h0 = h; g.iniTh = o->iniTh; g.minTh = o->minTh; g.lowTh = std::min(o->iniTh, o->minTh);
+    std::vector<Blur3Task> tiles3one;                         // one-tile k_blur3 tasks, appended behind the walks
     o->cells.clear(); o->tiles.clear(); o->tiles3.clear(); o->b3Th.clear(); o->b3Tv.clear(); o->strips.clear(); o->f3g.clear(); o->stripTile.clear(); o->stripQ.clear(); o->xt.clear(); o->yt.clear(); o->x4.clear(); for (auto& v : o->rzTasks) v.clear();
     size_t off = 0;
     int totalSlots = 0, totalSel = 0, maxN = 0;
@@ -233,6 +235,9 @@ static int build_geometry(orbx* o, int w, int h) {
             for (int t0 = 0; t0 < ntile; t0 += B3_CHUNK)
                 for (int sx = 0; sx < nstrip; sx += 4)                  // a workgroup = four adjacent strips
                     o->tiles3.push_back(Blur3Task{(short)l, (short)(sx * 32), (short)t0, (short)std::min(B3_CHUNK, ntile - t0), th0 + sx, tv0 + t0});
+            for (int t0 = 0; t0 < ntile; ++t0)
+                for (int sx = 0; sx < nstrip; sx += 4)
+                    tiles3one.push_back(Blur3Task{(short)l, (short)(sx * 32), (short)t0, 1, th0 + sx, tv0 + t0});
         }
         {
             static const u32 kSelB[4] = {0x05060700u, 0x07000100u, 0x01020100u, 0x03020100u};   // k = (w-1)&3 valid bytes-1
@@ -335,6 +340,8 @@ static int build_geometry(orbx* o, int w, int h) {
     if (ensure(&o->dL0, &o->capL0, (size_t)o->l0pitch * h * B)) return ORBX_E_HIP;
     if (ensure(&o->dCells, &o->capCells, o->cells.size())) return ORBX_E_HIP;
     if (ensure(&o->dTiles, &o->capTiles, o->tiles.size())) return ORBX_E_HIP;
+    o->nTiles3Walk = o->tiles3.size();
+    o->tiles3.insert(o->tiles3.end(), tiles3one.begin(), tiles3one.end());
     if (ensure(&o->dTiles3, &o->capTiles3, o->tiles3.size())) return ORBX_E_HIP;
     if (ensure(&o->dB3Th, &o->capB3Th, o->b3Th.size())) return ORBX_E_HIP;
     if (ensure(&o->dB3Tv, &o->capB3Tv, o->b3Tv.size())) return ORBX_E_HIP;
@@ -649,9 +656,14 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     if (o->blurV2)
         hipLaunchKernelGGL(k_blur2, dim3((unsigned)(o->tiles.size() + 3) / 4, nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
                            o->dTiles, (int)o->tiles.size(), o->blurSel);
-    else
-        hipLaunchKernelGGL(k_blur3, dim3((unsigned)o->tiles3.size(), nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
-                           o->dTiles3, (const uint4*)o->dB3Th, (const uint4*)o->dB3Tv);
+    else {
+        // big batches: workgroups walk B3_CHUNK tiles (prologue amortised); small ones: one tile per workgroup (8x the workgroups,
+        // an eighth of the latency -- the single-frame path)
+        const bool walk = (size_t)nimg * o->nTiles3Walk >= 2048;
+        const size_t first = walk ? 0 : o->nTiles3Walk, count = walk ? o->nTiles3Walk : o->tiles3.size() - o->nTiles3Walk;
+        hipLaunchKernelGGL(k_blur3, dim3((unsigned)count, nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
+                           o->dTiles3 + first, (const uint4*)o->dB3Th, (const uint4*)o->dB3Tv);
+    }
     HIPCHK(hipEventRecord(o->ev[9], s1));                        // blur ready
     if (o->qtV1)
         hipLaunchKernelGGL(k_quadtree, dim3(nimg, g.nlevels), dim3(256), o->qtLds, st, g, o->dCells, o->dCandCnt, o->dCandEnt,
