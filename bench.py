@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic frames generated per rank")
+    ap.add_argument("--match-stream", choices=["ex", "own"], default="ex",
+                    help="where the matcher's kernels run when one handle is in flight (see the step loop)")
     ap.add_argument("--match", choices=["window", "knn2"], default="knn2",
                     help="match leg: 'window' = the mono SearchByProjection window search of every frame's keypoints in the previous "
                          "frame (grid gather + Hamming, ORBmatcher.cc:2543-2612); 'knn2' = dense brute-force 2-NN (Frame.cc:1440-1480)")
@@ -101,15 +103,20 @@ def main():
     sf_host = ex.GetScaleFactors()
     inv_w = float(np.float32(64) / np.float32(W)); inv_h = float(np.float32(48) / np.float32(H))   # Frame.cc:401-402, identity undistortion
 
-    # one handle in flight: the matcher runs on the extractor's stream (batch i's match, then batch i+1's extraction, in order)
-    same_stream = NH == 1
+    # --match-stream ex: the matcher runs on the extractor's stream (batch i's match, then batch i+1's extraction, in order);
+    # own: on its own stream behind batch i's extraction, beside batch i+1's pyramid/FAST phase -- batch i+1 waits for it only
+    # before its first kernel that writes the result block (orbx_guard_results)
+    same_stream = NH == 1 and args.match_stream == "ex"
+    guard = NH == 1 and args.match_stream == "own"
     if same_stream:
         assert L.orbm_set_stream(mts[0].h, L.orbx_stream(exs[0].h)) == 0
 
     def step():
         for h in range(NH):
             # the next batch may overwrite result buffers the matcher of the previous step still reads
-            if not same_stream:
+            if guard:
+                L.orbx_guard_results(exs[h].h, L.orbm_stream(mts[h].h))
+            elif not same_stream:
                 L.orbx_stream_wait_other(exs[h].h, L.orbm_stream(mts[h].h))
             if h > 0:
                 L.orbx_stream_wait_other(exs[h].h, L.orbm_stream(mts[h - 1].h))

@@ -107,6 +107,11 @@ int orbx_mean_timings(orbx_t*, float* ms8, int* nsamples);
  * reading the result buffers of the previous batch). */
 int orbx_stream_wait_results(orbx_t*, void* other_stream);
 int orbx_stream_wait_other(orbx_t*, void* other_stream);
+/* finer form of orbx_stream_wait_other for a consumer that only READS the result block (keypoints, descriptors, counts) of
+ * the previous batch on `reader_stream`: the next batch starts at once and waits for the reader's work enqueued so far only
+ * before its first kernel that writes the result block -- a matcher on its own stream then runs beside the next batch's
+ * pyramid / FAST phase.  Call after enqueueing the reader's work and before the next orbx_extract_batch_async. */
+int orbx_guard_results(orbx_t*, void* reader_stream);
 /* SURVEY 8(f).4 image ingest -- replaces cv::cvtColor(im, gray, COLOR_{RGB,BGR,RGBA,BGRA}2GRAY) in Tracking::GrabImage*
  * (src/Tracking.cc:1264-1290, 1339-1348, 1393-1402).  nimg interleaved 8-bit colour images (src_space = ORBX_HOST | ORBX_DEVICE)
  * are converted into the caller's DEVICE buffers dst[i] (dst_stride bytes per row; a multiple of 16 lets orbx_extract_batch*

@@ -27,7 +27,7 @@ EXPORTS = [
     "orbx_create", "orbx_destroy", "orbx_last_error", "orbx_max_keypoints", "orbx_extract", "orbx_extract_batch",
     "orbx_extract_batch_async", "orbx_sync", "orbx_result_device", "orbx_result_fetch", "orbx_result_fetch_all", "orbx_level_size",
     "orbx_level_image", "orbx_scale_tables", "orbx_features_per_level", "orbx_level_candidates",
-    "orbx_level_selected", "orbx_last_timings", "orbx_set_stage_timing", "orbx_mean_timings", "orbx_stream_wait_results", "orbx_stream_wait_other", "orbx_gray_from_color", "orbx_remap_linear", "orbx_clahe", "orbx_algorithmic_bytes", "orbx_blur_in_pass", "orbx_stream", "orbx_dev_alloc",
+    "orbx_level_selected", "orbx_last_timings", "orbx_set_stage_timing", "orbx_mean_timings", "orbx_stream_wait_results", "orbx_stream_wait_other", "orbx_guard_results", "orbx_gray_from_color", "orbx_remap_linear", "orbx_clahe", "orbx_algorithmic_bytes", "orbx_blur_in_pass", "orbx_stream", "orbx_dev_alloc",
     "orbx_dev_free", "orbx_memcpy_h2d", "orbx_memcpy_d2h", "orbx_device_count",
     # include/orbm.h
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_sync", "orbm_stream", "orbm_set_stream", "orbm_hamming",
@@ -77,6 +77,7 @@ def lib():
         L.orbx_mean_timings.argtypes = [vp, vp, i32p]
         L.orbx_stream_wait_results.argtypes = [vp, vp]
         L.orbx_stream_wait_other.argtypes = [vp, vp]
+        L.orbx_guard_results.argtypes = [vp, vp]
         L.orbx_set_stage_timing.argtypes = [vp, C.c_int]
         L.orbx_clahe.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, vp, C.c_int]
         L.orbx_remap_linear.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int]

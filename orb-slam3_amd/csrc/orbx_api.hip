@@ -73,6 +73,7 @@ struct orbx {
     hipEvent_t evr[kRing][12] = {};
     hipEvent_t* ev = evr[0];
     hipEvent_t evDone = nullptr;
+    hipEvent_t evGuard = nullptr; bool guardPending = false;   // orbx_guard_results: a reader of the result block on another stream
     long nEnq = 0;
     u8 *dPyr = nullptr, *dBlur = nullptr, *dL0 = nullptr;
     const u8** dL0Ptr = nullptr;
@@ -486,6 +487,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
         for (auto& set : o->evr) for (auto& e : set) if (rc == ORBX_OK && hipEventCreate(&e) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
         for (auto& e : o->evLvl) if (rc == ORBX_OK && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
         if (rc == ORBX_OK && hipEventCreateWithFlags(&o->evDone, hipEventDisableTiming) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
+        if (rc == ORBX_OK && hipEventCreateWithFlags(&o->evGuard, hipEventDisableTiming) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
         if (rc) break;
         const size_t B = max_batch;
         if (hipMalloc((void**)&o->dL0Ptr, sizeof(u8*) * B) != hipSuccess || hipMalloc((void**)&o->dSelCnt, sizeof(u32) * 12 * B) != hipSuccess ||
@@ -526,6 +528,7 @@ void orbx_destroy(orbx_t* o) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& set : o->evr) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     if (o->evDone) (void)hipEventDestroy(o->evDone);
+    if (o->evGuard) (void)hipEventDestroy(o->evGuard);
     if (o->evH2D) (void)hipEventDestroy(o->evH2D);
     if (o->hPinned) (void)hipHostFree(o->hPinned);
     if (o->dIngest) (void)hipFree(o->dIngest);
@@ -678,6 +681,10 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
                                o->dDense, o->dKpNode, o->dSel, o->dSelCnt, o->dErr, o->maxCells);
     }
     STAGE_EV(3, st);
+    if (o->guardPending) {                                       // k_slots is the first writer of the result block (orbx_guard_results)
+        HIPCHK(hipStreamWaitEvent(st, o->evGuard, 0));
+        o->guardPending = false;
+    }
     hipLaunchKernelGGL(k_slots, dim3(nimg), dim3(256), 0, st, g, o->dSel, o->dSelCnt, o->dLap, o->dKps, o->dWork, o->dN, o->dMono);
     STAGE_EV(4, st);
     HIPCHK(hipStreamWaitEvent(st, o->ev[9], 0));
@@ -935,6 +942,14 @@ int orbx_stream_wait_results(orbx_t* o, void* other_stream) {
     HIPCHK(hipSetDevice(o->device));
     HIPCHK(hipEventRecord(o->evDone, o->stream));
     HIPCHK(hipStreamWaitEvent((hipStream_t)other_stream, o->evDone, 0));
+    return ORBX_OK;
+}
+
+int orbx_guard_results(orbx_t* o, void* reader_stream) {
+    if (!o) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    HIPCHK(hipEventRecord(o->evGuard, (hipStream_t)reader_stream));
+    o->guardPending = true;
     return ORBX_OK;
 }
 
