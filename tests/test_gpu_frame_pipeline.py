@@ -74,3 +74,50 @@ def test_mono_frame_construction_and_local_point_search(pkg, oracle, synth):
         assert got[0] == exp[0] and np.array_equal(got[1], exp[1]) and got[0] > 50
     finally:
         ex.close()
+
+
+def test_guarded_reader_overlaps_the_next_batch(pkg, oracle, synth):
+    # orbx_guard_results: a matcher on its own stream reads batch k's descriptors while batch k+1 is already being extracted;
+    # batch k+1 may overwrite the result block only after the reader has finished.  Many rounds with alternating inputs: the
+    # 2-NN of every round must be the one of that round's frames (oracle), never a mix with the next round's.
+    W, H, B = 752, 480, 4
+    sets = [[synth.gen_image(W, H, 500 + 10 * s + i) for i in range(B)] for s in range(2)]
+    stride = 768
+    bufs = []
+    for imgs in sets:
+        b = pkg.DeviceBuffer(stride * H * B)
+        for i, im in enumerate(imgs):
+            pad = np.zeros((H, stride), np.uint8); pad[:, :W] = im
+            b.upload(pad, i * stride * H)
+        bufs.append(b)
+    ex = pkg.ORBextractor(1000, max_size=(W, H), max_batch=B)
+    m = pkg.ORBmatcher()
+    L = ex.L
+    L.orbx_stream_wait_results.argtypes = [C.c_void_p, C.c_void_p]
+    L.orbm_stream.restype = C.c_void_p; L.orbm_stream.argtypes = [C.c_void_p]
+    ms = L.orbm_stream(m.h)
+    rounds = 6
+    cap = ex.result_device()["cap"]
+    outs = [(pkg.DeviceBuffer((B - 1) * cap * 8), pkg.DeviceBuffer((B - 1) * cap * 8)) for _ in range(rounds)]
+    for k in range(rounds):
+        ptrs = (C.c_void_p * B)(*[bufs[k & 1].ptr + i * stride * H for i in range(B)])
+        ex.enqueue_device(ptrs, W, H, stride, [(0, 0)] * B)
+        r = ex.result_device()
+        assert L.orbx_stream_wait_results(ex.h, ms) == 0
+        rc = L.orbm_knn2_batch_async(m.h, r["desc"] + cap * 32, cap, r["counts"] + 4, r["desc"], cap, r["counts"], B - 1, cap,
+                                     outs[k][0].ptr, outs[k][1].ptr)
+        assert rc == 0
+        assert L.orbx_guard_results(ex.h, ms) == 0
+    ex.sync(); m.sync()
+    want = []
+    for imgs in sets:
+        ref = oracle.Extractor(1000)
+        descs = [ref(im, (0, 0))[2] for im in imgs]
+        want.append([oracle.knn2(descs[i + 1], descs[i]) for i in range(B - 1)])
+    for k in range(rounds):
+        idx = outs[k][0].download(np.int32, (B - 1) * cap * 2).reshape(B - 1, cap, 2)
+        dist = outs[k][1].download(np.int32, (B - 1) * cap * 2).reshape(B - 1, cap, 2)
+        for i in range(B - 1):
+            ridx, rdist = want[k & 1][i]
+            n = len(ridx)
+            assert np.array_equal(idx[i, :n], ridx) and np.array_equal(dist[i, :n], rdist), (k, i)
