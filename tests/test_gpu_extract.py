@@ -86,16 +86,17 @@ def test_batch_equals_single(pkg, oracle, synth):
         assert kps.tobytes() == kps_ref.tobytes() and np.array_equal(desc, desc_ref)
 
 
-def test_large_batch_takes_the_tile_walking_blur(pkg, oracle, synth):
+@pytest.mark.parametrize("nframes", [48, 71])
+def test_large_batch_paths(pkg, oracle, synth, nframes):
     # from ~40 frames of this size on, k_blur3's workgroups walk eight tiles each instead of one (orbx_api.hip: `walk`);
     # every frame of such a batch -- odd one out included -- must still equal the oracle
-    imgs = [synth.gen_image(752, 480, 900 + (i % 5)) for i in range(47)] + [synth.gen_image(752, 480, 3, "lowcontrast")]
+    imgs = [synth.gen_image(752, 480, 900 + (i % 5)) for i in range(nframes - 1)] + [synth.gen_image(752, 480, 3, "lowcontrast")]
     ex = pkg.ORBextractor(1000, max_size=(752, 480), max_batch=len(imgs))
     res = ex.extract_batch(imgs, [(0, 0)] * len(imgs))
     ref = oracle.Extractor(1000)
     want = {}
     for i, img in enumerate(imgs):
-        key = 900 + (i % 5) if i < 47 else -1
+        key = 900 + (i % 5) if i < nframes - 1 else -1
         if key not in want:
             want[key] = ref(img, (0, 0))
         n_ref, kps_ref, desc_ref, mono_ref = want[key]
