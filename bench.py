@@ -1,64 +1,391 @@
 #!/usr/bin/env python3
-"""bench.py -- ORB extract+match frames/sec @752x480, 1000 features (BASELINE.json metric).
+"""bench.py -- ORB extract+match frames/sec (BASELINE.json metric) on N MI355X.
 
-One step = one pass of the hot path over one batch of B synthetic frames already resident in HBM:
-  extraction of every frame (8-level pyramid, FAST, quadtree, orientation, blur, rBRIEF) followed by the
-  Hamming match of each frame's descriptors against the previous frame's (dense 2-NN, orbm_knn2).
-N GPUs = N processes (torch.distributed / RCCL), each with its own B frames ("weak" scaling); the only
-collective is the all_gather of per-frame keypoint counts after the timed steps' last batch.
+One step = one pass of the hot path over one batch of synthetic frames already resident in HBM.  Workloads (--config):
+  c2 (default, the headline: configs[1])  752x480, 1000 features, 512 frames/GPU/step: extraction of every frame (8-level
+      pyramid, FAST, quadtree, orientation, blur, rBRIEF) + dense 2-NN Hamming match of each frame against the previous one.
+  c5  1920x1080, 4000 features, 64 frames/GPU/step, same step (the roofline run of SURVEY 8(d)).
+  c4  TUM-VI geometry: 8 fisheye stereo pairs of 512x512, 1500 features per image: 2 extractions + the brute-force 2-NN of
+      ComputeStereoFishEyeMatches (Frame.cc:1440-1480) per pair.
+  c3  EuRoC stereo: pairs of 752x480, 1200 features: 2 extractions + ComputeStereoMatches (Frame.cc:1027-1276) per pair + one
+      SearchForTriangulation bucket match against the previous pair (LocalMapping.cc:592).
+`value` counts what SURVEY 8(d) specifies: all kernels + the copy of every frame's keypoints / descriptors / counts to (pinned)
+host memory, which runs on a copy stream beside the next batch; `value_device_resident` is the same loop without that copy.
+
+N GPUs = N processes (torch.distributed over RCCL), each with its own frames ("weak" scaling); the only collective is the
+all_gather of per-frame keypoint counts.  `python bench.py --gpus N` starts the N ranks itself (fresh child processes, spawned
+before this process touches torch or HIP); under torchrun (RANK / WORLD_SIZE set) it is one of the ranks.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline"     -- pyramid+FAST pass: algorithmic bytes / HIP-event time of those launches
-  "cpu_baseline" -- the CPU oracle (a port, 1 thread) on a bounded sample of the same frames.
+  "roofline"     -- pyramid+FAST(+blur) pass: algorithmic bytes / live HIP-event span of those launches
+  "cpu_baseline" -- the CPU oracle (a port, 1 thread) on a bounded sample of the same frames (+ an nproc-thread context figure).
 """
 import argparse
 import ctypes as C
+import gc
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-
 HBM_PEAK_GBS = 8000.0       # MI355X spec (MI355X_MICROARCH.md): 8.0 TB/s; 6.29 TB/s measured copy peak
 
+CONFIGS = {
+    #        W     H     nF    frames/step  lapping       what
+    "c2": (752, 480, 1000, 512, (0, 1000), "configs[1]"),
+    "c5": (1920, 1080, 4000, 64, (0, 1000), "configs[4]"),
+    "c4": (512, 512, 1500, 16, (0, 511), "configs[3]"),
+    "c3": (752, 480, 1200, 128, (0, 0), "configs[2]"),
+}
 
-def main():
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step (a larger batch amortises the dependent resize chain and the latency-bound quadtree)")
-    ap.add_argument("--width", type=int, default=752)
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (0 = the config's default)")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--nfeatures", type=int, default=0)
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic frames generated per rank")
-    ap.add_argument("--match-stream", choices=["ex", "own"], default="ex",
-                    help="where the matcher's kernels run when one handle is in flight (see the step loop)")
+    ap.add_argument("--launch", choices=["graph", "eager"], default="graph",
+                    help="graph: the step's whole enqueue sequence is captured once and replayed with one hipGraphLaunch per step")
     ap.add_argument("--match", choices=["window", "knn2"], default="knn2",
-                    help="match leg: 'window' = the mono SearchByProjection window search of every frame's keypoints in the previous "
-                         "frame (grid gather + Hamming, ORBmatcher.cc:2543-2612); 'knn2' = dense brute-force 2-NN (Frame.cc:1440-1480)")
-    ap.add_argument("--handles", type=int, default=1, help="extractor handles kept in flight per GPU (the batch is split over them)")
+                    help="c2/c5 match leg: 'knn2' = dense brute-force 2-NN (Frame.cc:1440-1480); 'window' = the mono SearchByProjection "
+                         "window search of every keypoint in the previous frame (eager launch only)")
     ap.add_argument("--cpu-sample", type=int, default=96, help="frames timed through the CPU oracle (0 = skip)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` outside torchrun starts N fresh rank processes (nothing GPU-related has been imported here)
+# ----------------------------------------------------------------------------------------------------------------------
+def launch_ranks(n, argv):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed: %s\n" % bad)
+        return 1
+    return 0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the workloads
+# ----------------------------------------------------------------------------------------------------------------------
+class StubWorkload:
+    """ORB_BENCH_STUB=1: no GPU, no HIP library -- the launcher / rendezvous / max-over-ranks / count-gather path on CPU."""
+    kind = "stub"
+
+    def __init__(self, args, rank, local_rank):
+        self.B = args.batch or 4
+        self.rank = rank
+
+    def prime(self):
+        pass
+
+    def step(self):
+        time.sleep(0.002)
+
+    def flush(self):
+        pass
+
+    def sync(self):
+        pass
+
+    def counts(self):
+        import numpy as np
+        return np.full(self.B, 1000 + self.rank, np.int32)
+
+
+class OrbWorkload:
+    """Extraction of a batch + the config's match leg, all through the C ABI (ctypes)."""
+    kind = "orb"
+
+    def __init__(self, args, rank, local_rank):
+        import numpy as np
+        self.np = np
+        pkg = importlib.import_module("orb-slam3_amd")
+        synth = importlib.import_module("orb-slam3_amd.synth")
+        self.pkg, self.L = pkg, pkg.lib()
+        L = self.L
+        cw, ch, cnf, cb, lap, _ = CONFIGS[args.config]
+        self.W, self.H = args.width or cw, args.height or ch
+        self.nF, self.B = args.nfeatures or cnf, args.batch or cb
+        self.cfg, self.args, self.lap = args.config, args, lap
+        W, H, B = self.W, self.H, self.B
+        if self.cfg in ("c3", "c4") and B % 2:
+            raise SystemExit("stereo configs take an even number of frames per step")
+        self.ex = pkg.ORBextractor(self.nF, 1.2, 8, 20, 7, device=local_rank, max_size=(W, H), max_batch=B)
+        self.mt = pkg.ORBmatcher(0.7, device=local_rank)
+        ex, mt = self.ex, self.mt
+        self.cap = cap = ex.cap
+        # ---- inputs resident in HBM before the timed region
+        self.stride = stride = (W + 63) // 64 * 64
+        nd = max(1, min(args.distinct, B))
+        if self.cfg in ("c3", "c4"):                            # stereo: frames 0..B/2-1 are the left images, B/2.. the right ones
+            pairs = [synth.gen_stereo_pair(W, H, 1000 * rank + 100 + i) for i in range(max(1, nd // 2))]
+            lefts = [p[0] for p in pairs]; rights = [p[1] for p in pairs]
+            self.host_imgs = [lefts[i % len(lefts)] for i in range(B // 2)] + [rights[i % len(rights)] for i in range(B // 2)]
+        else:
+            base = [synth.gen_image(W, H, 1000 * rank + 1 + i) for i in range(nd)]
+            self.host_imgs = [base[i % nd] for i in range(B)]
+        self.dev = pkg.DeviceBuffer(stride * H * B)
+        padded = np.zeros((H, stride), np.uint8)
+        for i in range(B):
+            padded[:, :W] = self.host_imgs[i]
+            self.dev.upload(padded, offset=i * stride * H)
+        self.ptrs = (C.c_void_p * B)(*[int(self.dev.ptr + i * stride * H) for i in range(B)])
+        self.laps = np.tile(np.array(lap, np.int32), B)
+        self.res = []                                           # device pointers of the two result blocks (alternated step by step)
+        for blk in (0, 1):
+            L.orbx_set_result_block(ex.h, blk)
+            self.res.append(ex.result_device())
+        L.orbx_set_result_block(ex.h, 0)
+        self.idx2 = pkg.DeviceBuffer(B * cap * 2 * 4); self.dist2 = pkg.DeviceBuffer(B * cap * 2 * 4)
+        if args.match == "window":
+            self.gstart = pkg.DeviceBuffer(B * 3073 * 4); self.gidx = pkg.DeviceBuffer(B * cap * 4); self.sdist = pkg.DeviceBuffer(B * cap * 4)
+            self.sf_host = ex.GetScaleFactors()
+            self.inv_w = float(np.float32(64) / np.float32(W)); self.inv_h = float(np.float32(48) / np.float32(H))   # Frame.cc:401-402
+        # ---- where the results land on the host: pinned, one block per array (reused every step, like a Frame's mvKeys)
+        self.h_kps = [pkg.PinnedBuffer(28 * cap * B) for _ in (0, 1)]; self.h_desc = [pkg.PinnedBuffer(32 * cap * B) for _ in (0, 1)]
+        self.h_n = [pkg.PinnedBuffer(4 * B) for _ in (0, 1)]; self.h_mono = [pkg.PinnedBuffer(4 * B) for _ in (0, 1)]
+        self.download = True
+        self.graph = args.launch == "graph" and args.match == "knn2"
+        self.nslots = 4
+        self.captured = False
+        self.k = 0
+        # the matcher's kernels run on the extractor's stream (batch i's match, then batch i+1's extraction, in order): they are
+        # then part of the captured sequence too
+        assert L.orbm_set_stream(mt.h, L.orbx_stream(ex.h)) == 0
+        L.orbx_set_stage_timing(ex.h, 0)
+
+    # ---- one step's kernels (what a graph slot holds): extraction into result block `blk` + the match leg on that block
+    def _enqueue(self, blk):
+        L, ex, mt, r, B, cap = self.L, self.ex, self.mt, self.res[blk], self.B, self.cap
+        L.orbx_set_result_block(ex.h, blk)
+        ex.enqueue_device(self.ptrs, self.W, self.H, self.stride, self.laps)
+        if self.cfg in ("c2", "c5"):
+            if self.args.match == "window" and B > 1:
+                rc = L.orbm_grid_build_batch_async(mt.h, r["kps"], r["counts"], B, cap, 0.0, 0.0, self.inv_w, self.inv_h, self.gstart.ptr, self.gidx.ptr)
+                assert rc == 0, rc
+                rc = L.orbm_track_window_batch_async(mt.h, r["kps"], r["desc"], r["counts"], cap, self.gstart.ptr, self.gidx.ptr,
+                                                     0.0, 0.0, self.inv_w, self.inv_h, 1, 0, B - 1, 15.0,
+                                                     self.sf_host.ctypes.data_as(C.c_void_p), 8, 0.0, 0.0,
+                                                     self.idx2.ptr, self.dist2.ptr, self.sdist.ptr)
+                assert rc == 0, rc
+            elif B > 1:          # dense 2-NN of frame i (query) against frame i-1 (train): B-1 pairs
+                rc = L.orbm_knn2_batch_async(mt.h, r["desc"] + cap * 32, cap, r["counts"] + 4, r["desc"], cap, r["counts"],
+                                             B - 1, cap, self.idx2.ptr + cap * 8, self.dist2.ptr + cap * 8)
+                assert rc == 0, rc
+        elif self.cfg == "c4":   # ComputeStereoFishEyeMatches: left descriptors (query) x right descriptors (train) of the same pair
+            P = B // 2
+            rc = L.orbm_knn2_batch_async(mt.h, r["desc"], cap, r["counts"], r["desc"] + P * cap * 32, cap, r["counts"] + 4 * P,
+                                         P, cap, self.idx2.ptr, self.dist2.ptr)
+            assert rc == 0, rc
+        else:
+            self._enqueue_c3()
+
+    def _enqueue_c3(self):
+        raise SystemExit("config c3 needs the batched stereo path (not in this build)")
+
+    def _capture(self):
+        L, ex = self.L, self.ex
+        for slot in range(self.nslots):                         # slot s writes result block s & 1
+            rc = L.orbx_capture_begin(ex.h, slot)
+            assert rc == 0, (rc, L.orbx_last_error())
+            self._enqueue(slot & 1)
+            rc = L.orbx_capture_end(ex.h)
+            assert rc == 0, (rc, L.orbx_last_error())
+        self.captured = True
+
+    def prime(self):
+        """Untimed setup: every code path of the timed loop runs once (eager enqueue, graph capture + replay, download)."""
+        graph, self.graph = self.graph, False
+        for _ in range(2):
+            self.step()
+        self.sync()
+        self.graph = graph
+        if self.graph:
+            self._capture()
+            for _ in range(self.nslots):
+                self.step()
+            self.sync()
+
+    def step(self):
+        """Batch k goes into result block k & 1; its results leave for the host (copy stream) beside batch k+1, which writes the
+        other block; batch k+2 waits on the device for that copy before it rewrites the block."""
+        blk = self.k & 1
+        if self.graph:
+            rc = self.L.orbx_graph_launch(self.ex.h, self.k % self.nslots)
+            assert rc == 0, rc
+        else:
+            self._enqueue(blk)
+        if self.download:
+            rc = self.L.orbx_result_download_async(self.ex.h, self.h_kps[blk].ptr, self.h_desc[blk].ptr, self.h_n[blk].ptr, self.h_mono[blk].ptr, self.B)
+            assert rc == 0, rc
+        self.k += 1
+
+    def flush(self):
+        pass
+
+    def sync(self):
+        self.ex.sync()
+        self.mt.sync()
+
+    def counts(self):
+        """per-frame keypoint counts of the most recent batch, straight from the device"""
+        out = self.np.zeros(self.B, self.np.int32)
+        self.L.orbx_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.res[(self.k - 1) & 1]["counts"], 4 * self.B)
+        return out
+
+    def mark(self, which):
+        self.L.orbx_mark(self.ex.h, which)
+
+    def mark_ms(self):
+        t = C.c_float()
+        rc = self.L.orbx_mark_elapsed_ms(self.ex.h, C.byref(t))
+        assert rc == 0, rc
+        return t.value
+
+
+def timed_loop(wl, steps, barrier):
+    """EXACTLY `steps` steps between two barriers; returns (wall seconds, host seconds spent enqueueing)."""
+    gc.collect()
+    gc.disable()
+    try:
+        barrier()
+        if hasattr(wl, "mark"):
+            wl.mark(0)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            wl.step()
+        wl.flush()
+        t_enq = time.perf_counter() - t0
+        if hasattr(wl, "mark"):
+            wl.mark(1)
+        wl.sync()
+        barrier()
+        dt = time.perf_counter() - t0
+    finally:
+        gc.enable()
+    return dt, t_enq
+
+
+def cpu_baseline(wl, args):
+    """The oracle (test infrastructure, a port of the reference's CPU algorithm) timed on this box's host cores."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orbref
+    pkg = wl.pkg
+    W, H, nF, lap = wl.W, wl.H, wl.nF, wl.lap
+    ns = args.cpu_sample
+    imgs = wl.host_imgs
+    out = {}
+
+    def run_stream(ref, frames, match=True):
+        prev = None
+        OM = orbref._oracle_matcher_class()() if args.match == "window" else None
+        for i in frames:
+            n, kps, desc, mono = ref(imgs[i % len(imgs)], lap)
+            if match and prev is not None:
+                if args.match == "knn2":
+                    orbref.knn2(desc, prev[1])
+                else:                                   # the oracle's SearchByProjection(Frame,Frame) in C over the same windows
+                    fv = pkg.FrameView(prev[0], prev[1], W, H, backend=OM)
+                    nq = len(kps)
+                    OM.SearchByProjectionFrame(fv, np.zeros(fv.n, np.uint8), ref.tables()["sf"], np.ones(nq, np.uint8), kps["x"], kps["y"],
+                                               np.zeros(nq, np.float32), kps["octave"], kps["angle"], desc, np.zeros(nq, np.uint8), 15.0)
+            prev = (kps, desc)
+
+    if wl.cfg in ("c2", "c5"):
+        ref = orbref.Extractor(nF, 1.2, 8, 20, 7)
+        tc = time.perf_counter()
+        run_stream(ref, range(ns))
+        tcpu = time.perf_counter() - tc
+        out["cpu_baseline"] = {"value": ns / tcpu, "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": "%d frames of the same synthetic stream through oracle/liborbref.so "
+                                         "(extract + %s match vs previous frame), 1 thread" % (ns, args.match),
+                               "stage_ms_per_frame": {k: v / ns for k, v in ref.stage_ms().items()}}
+        # context figure: frame-parallel over every host core of this box, one oracle extractor per thread
+        nthr = max(1, min(os.cpu_count() or 1, 64))
+        per = max(2, ns // 4)
+        refs = [orbref.Extractor(nF, 1.2, 8, 20, 7) for _ in range(nthr)]
+        thr = [threading.Thread(target=run_stream, args=(refs[t], range(t * per, (t + 1) * per))) for t in range(nthr)]
+        tc = time.perf_counter()
+        for t in thr:
+            t.start()
+        for t in thr:
+            t.join()
+        tpar = time.perf_counter() - tc
+        out["cpu_context_all_cores"] = {"value": nthr * per / tpar, "unit": "frames/s", "cores": nthr, "kind": "port",
+                                        "sample": "%d threads x %d frames each (every thread its own stream and oracle extractor)" % (nthr, per)}
+    elif wl.cfg == "c4":
+        # the reference starts the two extractions of a stereo frame on two threads (Frame.cc:132-137 / 1363-1364); then the
+        # brute-force 2-NN of left x right (Frame.cc:1458)
+        P = max(1, ns // 8)
+        refs = [orbref.Extractor(nF, 1.2, 8, 20, 7) for _ in range(2)]
+        half = wl.B // 2
+        tc = time.perf_counter()
+        for p in range(P):
+            res = [None, None]
+
+            def one(side, idx):
+                res[side] = refs[side](imgs[idx], lap)
+            th = [threading.Thread(target=one, args=(0, p % half)), threading.Thread(target=one, args=(1, half + p % half))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            orbref.knn2(res[0][2], res[1][2])
+        tcpu = time.perf_counter() - tc
+        out["cpu_baseline"] = {"value": 2 * P / tcpu, "unit": "frames/s", "cores": 2, "kind": "port",
+                               "sample": "%d stereo pairs of the same synthetic stream through oracle/liborbref.so: two extractions on two "
+                                         "threads (Frame.cc:1363-1364), then the 2-NN of left x right on one" % P}
+    return out
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    stub = os.environ.get("ORB_BENCH_STUB") == "1"
 
+    import numpy as np
     import torch                       # plumbing: device sync + torch.distributed (RCCL); imported BEFORE the
     import torch.distributed as dist   # HIP library so both share one libamdhip64 runtime
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    ndev = torch.cuda.device_count()
-    local_rank = local_rank % max(ndev, 1)             # rehearsals may put several ranks on one GPU (gloo only)
-    torch.cuda.set_device(local_rank)
-    backend = os.environ.get("ORB_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; "gloo" only for single-GPU rehearsals
+    backend = os.environ.get("ORB_BENCH_BACKEND", "gloo" if stub else "nccl")   # "nccl" IS RCCL on ROCm; "gloo" for rehearsals
+    if not stub:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        ndev = torch.cuda.device_count()
+        local_rank = local_rank % max(ndev, 1)             # rehearsals may put several ranks on one GPU (gloo only)
+        torch.cuda.set_device(local_rank)
     cdev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -67,244 +394,172 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    pkg = importlib.import_module("orb-slam3_amd")
-    synth = importlib.import_module("orb-slam3_amd.synth")
-    L = pkg.lib()
-
-    W, H, B = args.width, args.height, args.batch
-    # The batch of B frames is split over `--handles` extractor handles (own streams + scratch each) that are kept in
-    # flight together: while one half-batch is in its latency-bound quadtree/descriptor kernels the other one runs the
-    # VALU-bound FAST kernel.  No host sync inside a step: matcher streams wait on extractor streams through events.
-    NH = max(1, min(args.handles, B))
-    sizes = [B // NH + (1 if i < B % NH else 0) for i in range(NH)]
-    exs = [pkg.ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=local_rank, max_size=(W, H), max_batch=sz) for sz in sizes]
-    mts = [pkg.ORBmatcher(0.7, device=local_rank) for _ in range(NH)]
-    ex = exs[0]
-    cap = ex.cap
-
-    # ---- inputs resident in HBM before the timed region
-    stride = (W + 63) // 64 * 64
-    host_imgs = [synth.gen_image(W, H, 1000 * rank + 1 + i) for i in range(min(args.distinct, B))]
-    dev = pkg.DeviceBuffer(stride * H * B)
-    padded = np.zeros((H, stride), np.uint8)
-    for i in range(B):
-        padded[:, :W] = host_imgs[i % len(host_imgs)]
-        dev.upload(padded, offset=i * stride * H)
-    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
-    ptrs = [(C.c_void_p * sizes[h])(*[int(dev.ptr + int(offs[h] + i) * stride * H) for i in range(sizes[h])]) for h in range(NH)]
-    laps = [np.tile(np.array([0, 1000], np.int32), sizes[h]) for h in range(NH)]   # monocular call: vLapping = {0,1000} (Frame.cc:361)
-    res = [e.result_device() for e in exs]
-    idx2 = [pkg.DeviceBuffer(max(1, sizes[h]) * cap * 2 * 4) for h in range(NH)]
-    dist2 = [pkg.DeviceBuffer(max(1, sizes[h]) * cap * 2 * 4) for h in range(NH)]
-    xidx = pkg.DeviceBuffer(NH * cap * 2 * 4); xdist = pkg.DeviceBuffer(NH * cap * 2 * 4)
-    gstart = [pkg.DeviceBuffer(max(1, sizes[h]) * 3073 * 4) for h in range(NH)]
-    gidx = [pkg.DeviceBuffer(max(1, sizes[h]) * cap * 4) for h in range(NH)]
-    sdist = [pkg.DeviceBuffer(max(1, sizes[h]) * cap * 4) for h in range(NH)]
-    sf_host = ex.GetScaleFactors()
-    inv_w = float(np.float32(64) / np.float32(W)); inv_h = float(np.float32(48) / np.float32(H))   # Frame.cc:401-402, identity undistortion
-
-    # --match-stream ex: the matcher runs on the extractor's stream (batch i's match, then batch i+1's extraction, in order);
-    # own: on its own stream behind batch i's extraction, beside batch i+1's pyramid/FAST phase -- batch i+1 waits for it only
-    # before its first kernel that writes the result block (orbx_guard_results)
-    same_stream = NH == 1 and args.match_stream == "ex"
-    guard = NH == 1 and args.match_stream == "own"
-    if same_stream:
-        assert L.orbm_set_stream(mts[0].h, L.orbx_stream(exs[0].h)) == 0
-
-    def step():
-        for h in range(NH):
-            # the next batch may overwrite result buffers the matcher of the previous step still reads
-            if guard:
-                L.orbx_guard_results(exs[h].h, L.orbm_stream(mts[h].h))
-            elif not same_stream:
-                L.orbx_stream_wait_other(exs[h].h, L.orbm_stream(mts[h].h))
-            if h > 0:
-                L.orbx_stream_wait_other(exs[h].h, L.orbm_stream(mts[h - 1].h))
-            exs[h].enqueue_device(ptrs[h], W, H, stride, laps[h])
-        for h in range(NH):
-            ms = L.orbm_stream(mts[h].h)
-            if not same_stream:
-                L.orbx_stream_wait_results(exs[h].h, ms)
-            r = res[h]
-            if args.match == "window":
-                # Frame grid (M14) for every frame, then each frame's keypoints search the previous frame inside the
-                # SearchByProjection window th=15 (mono, Tracking.cc:3203-3208); frames of other handles are skipped here
-                rc = L.orbm_grid_build_batch_async(mts[h].h, r["kps"], r["counts"], sizes[h], cap, 0.0, 0.0, inv_w, inv_h,
-                                                   gstart[h].ptr, gidx[h].ptr)
-                assert rc == 0, rc
-                if sizes[h] > 1:
-                    rc = L.orbm_track_window_batch_async(mts[h].h, r["kps"], r["desc"], r["counts"], cap, gstart[h].ptr, gidx[h].ptr,
-                                                         0.0, 0.0, inv_w, inv_h, 1, 0, sizes[h] - 1, 15.0,
-                                                         sf_host.ctypes.data_as(C.c_void_p), 8, 0.0, 0.0,
-                                                         idx2[h].ptr, dist2[h].ptr, sdist[h].ptr)
-                    assert rc == 0, rc
-                continue
-            # dense 2-NN Hamming match of frame i (query) against frame i-1 (train) inside the half-batch ...
-            if sizes[h] > 1:
-                rc = L.orbm_knn2_batch_async(mts[h].h, r["desc"] + cap * 32, cap, r["counts"] + 4, r["desc"], cap, r["counts"],
-                                             sizes[h] - 1, cap, idx2[h].ptr + cap * 8, dist2[h].ptr + cap * 8)
-                assert rc == 0, rc
-            # ... and of its first frame against the last frame of the previous half-batch (B-1 pairs in total)
-            if h > 0:
-                L.orbx_stream_wait_results(exs[h - 1].h, ms)
-                p = res[h - 1]
-                rc = L.orbm_knn2_batch_async(mts[h].h, r["desc"], cap, r["counts"], p["desc"] + (sizes[h - 1] - 1) * cap * 32, cap,
-                                             p["counts"] + 4 * (sizes[h - 1] - 1), 1, cap, xidx.ptr + h * cap * 8, xdist.ptr + h * cap * 8)
-                assert rc == 0, rc
-
-    def sync_all():
-        for e in exs:
-            e.sync()
-        for m in mts:
-            m.sync()
-
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
-    # the timed steps record only the dependency events (start, end of the pyramid+FAST pass, end of the batch): the
-    # roofline span is measured live on them; the per-stage breakdown comes from a short untimed pass afterwards
-    for e in exs:
-        L.orbx_set_stage_timing(e.h, 0)
+    wl = (StubWorkload if stub else OrbWorkload)(args, rank, local_rank)
+    B = wl.B
+    wl.prime()
     for _ in range(args.warmup):
-        step()
-    sync_all()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    barrier()
-    dt = time.perf_counter() - t0
+        wl.step()
+    wl.sync()
+    dt, t_enq = timed_loop(wl, args.steps, barrier)          # the metric: kernels + results to the host
+    gpu_wall = wl.mark_ms() if not stub else None
+    extra = {}
+    if not stub:
+        # HIP-event times of the timed steps (recorded on the streams the kernels were launched on; in graph mode the latest
+        # replay of every graph slot, i.e. the last steps of the timed region)
+        tm, nsamp = wl.ex.mean_timings()
+        span_ms, total_ms = tm["pyramid_fast_span"], tm["total"]
+        match_ms = wl.mt.timing_ms()
+        # the same loop with the results left in HBM (round-1's figure)
+        wl.download = False
+        for _ in range(4):
+            wl.step()
+        wl.sync()
+        dt_res, _ = timed_loop(wl, args.steps, barrier)
+        wl.download = True
+        extra = dict(span_ms=span_ms, total_ms=total_ms, match_ms=match_ms, nsamp=nsamp, dt_res=dt_res)
 
-    # HIP-event times of the timed steps (events recorded on the streams the kernels were launched on)
-    t_all = []
-    for e, sz in zip(exs, sizes):
-        tm, ns = e.mean_timings()
-        t_all.append((tm, sz))
-    span_timed = [tm["pyramid_fast_span"] for tm, _ in t_all]
-    total_timed = [tm["total"] for tm, _ in t_all]
-    for e in exs:                                             # stage breakdown: same steps again with every stage event, untimed
-        L.orbx_set_stage_timing(e.h, 1)
-    for _ in range(max(3, min(8, args.steps))):
-        step()
-    sync_all()
-    t_all = []
-    for e, sz, sp_t, tot_t in zip(exs, sizes, span_timed, total_timed):
-        tm, ns = e.mean_timings()
-        tm["pyramid_fast_span_staged"] = tm["pyramid_fast_span"]
-        tm["pyramid_fast_span"] = sp_t; tm["total"] = tot_t     # the live figures of the timed steps
-        t_all.append((tm, sz))
-    t_pyr = [sum(tm["pyramid_fast_span"] for tm, _ in t_all) / len(t_all)]
-    t_fast = [0.0]
-    mt = mts[0]
-    n_host = np.zeros(B, np.int32)                         # keypoint counts of the last batch
-    for h in range(NH):
-        part = np.zeros(sizes[h], np.int32)
-        L.orbx_memcpy_d2h(part.ctypes.data_as(C.c_void_p), res[h]["counts"], 4 * sizes[h])
-        n_host[offs[h]:offs[h + 1]] = part
+    n_host = wl.counts()
     dmod = importlib.import_module("orb-slam3_amd.dist")
-    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    tmax = torch.tensor([dt, extra.get("dt_res", 0.0)], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     # RCCL: the path's only exchange -- per-frame keypoint counts of every rank
     gathered = dmod.gather_counts(n_host, device=cdev)
-    total_kp = torch.stack([g.sum() for g in gathered]).sum()
-    dt = float(tmax.item())
+    total_kp = int(torch.stack([g.sum() for g in gathered]).sum().item())
+    dt, dt_res = float(tmax[0].item()), float(tmax[1].item())
 
     if rank == 0:
         frames = B * args.steps * world
-        alg, fused = ex.algorithmic_bytes()
-        # the blur's compulsory traffic is 2 * (sum of level pixels) = 2 * (alg - fused); it belongs to the pass
-        # when the blur is scheduled inside it (default: matrix-core blur behind the resize chain, beside FAST) -- the span
-        # then ends with the later of FAST and blur
-        blur_in = ex.blur_in_pass()
-        alg_pf = alg
-        if blur_in:
-            alg = alg + 2 * (alg - fused)
-        # every handle processes its share of the batch concurrently: per-launch-group figure = bytes of ONE handle's
-        # frames / that handle's own pyramid+FAST wall span (conservative: the spans overlap other handles' kernels)
-        pf_ms = float(np.mean(t_pyr) + np.mean(t_fast))
-        achieved = alg * (B / NH) / (pf_ms * 1e-3) / 1e9
-        traffic = None                                      # HBM bytes/launch-group from the committed rocprofv3 --pmc passes
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            c = tj["config"]
-            if (c["width"], c["height"], c["nfeatures"]) == (W, H, args.nfeatures):
-                traffic = (tj["pyramid_fast_bytes_per_frame"] + (tj["blur_bytes_per_frame"] if blur_in else 0)) * (B / NH)
-        except Exception:
-            traffic = None
-        stage = {k: float(np.mean([tm[k] for tm, _ in t_all])) for k in t_all[0][0]}
-        stage["match_" + args.match] = mt.timing_ms()
-        # secondary denominator: the device-to-device copy rate this GPU actually reaches, measured here with a
-        # 1 GiB torch copy (read + write bytes / time), outside the timed region
-        copy_gbs = None
-        try:
-            n = 1 << 30
-            a = torch.empty(n, dtype=torch.uint8, device=cdev); b = torch.empty_like(a)
-            b.copy_(a); torch.cuda.synchronize()
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                b.copy_(a)
-            e1.record(); torch.cuda.synchronize()
-            copy_gbs = 2.0 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-            del a, b
-        except Exception:
-            copy_gbs = None
         out = {
-            "metric": "ORB extract+match frames/sec @%dx%d, %d feat" % (W, H, args.nfeatures),
-            "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": None, "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("configs[1]: " if (W, H, args.nfeatures) == (752, 480, 1000) else "other size (not the headline config): ") +
-                                   "%dx%d grayscale, %d features, 8 levels, scale 1.2, FAST 20/7; "
-                                   "batch of %d frames/GPU/step resident in HBM; extract + %s against the previous frame"
-                                   % (W, H, args.nfeatures, B, "Frame grid build and SearchByProjection window match (th=15) of every keypoint"
-                                      if args.match == "window" else "dense 2-NN Hamming match (int8 MFMA)"),
-                       "frames_per_step_per_gpu": B, "handles_in_flight": NH, "keypoints_last_batch": int(total_kp.item())},
-            "roofline": {"bound": "hbm", "kernel": ("pyramid+FAST+blur pass (k_resize2 x7 then k_blur3 on stream 2 + k_fast3 x3 and k_fast_fix on stream 1; wall span by HIP events)"
-                                    if blur_in else "pyramid+FAST pass (k_resize2 x7 on stream 2 + k_fast3 x3 and k_fast_fix on stream 1; wall span by HIP events)"),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg * (B / NH), "frames_per_launch": B / NH, "algorithmic_bytes_per_frame": alg, "fused_lower_bound_per_frame": fused,
-                         "launch_ms": pf_ms, "measured_copy_peak_GBps": copy_gbs,
-                         # for continuity with the pyramid+FAST-only figure: its own bytes over the span to the end of the last FAST
-                         # launch (stage events of the untimed staged pass; FAST is stretched by the blur running beside it)
-                         "pyramid_fast_only": ({"algorithmic_bytes_per_frame": alg_pf, "span_ms": stage["fast"],
-                                                "achieved": alg_pf * (B / NH) / (stage["fast"] * 1e-3) / 1e9,
-                                                "frac": alg_pf * (B / NH) / (stage["fast"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                                               if blur_in and stage.get("fast", 0) > 0 else None),
-                         "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None},
-            "stage_ms_per_step": stage,
         }
-        if world == 1 and args.cpu_sample > 0:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import orbref                                   # the checker, timed as the CPU baseline ("port")
-            ref = orbref.Extractor(args.nfeatures, 1.2, 8, 20, 7)
-            OM = orbref._oracle_matcher_class()()
-            ns = args.cpu_sample
-            prev = None
-            tc = time.perf_counter()
-            for i in range(ns):
-                n, kps, desc, mono = ref(host_imgs[i % len(host_imgs)], (0, 1000))
-                if prev is not None:
-                    if args.match == "knn2":
-                        orbref.knn2(desc, prev[1])
-                    else:                                   # the oracle's SearchByProjection(Frame,Frame) in C over the same windows
-                        fv = pkg.FrameView(prev[0], prev[1], W, H, backend=OM)
-                        nq = len(kps)
-                        OM.SearchByProjectionFrame(fv, np.zeros(fv.n, np.uint8), ref.tables()["sf"], np.ones(nq, np.uint8), kps["x"], kps["y"],
-                                                   np.zeros(nq, np.float32), kps["octave"], kps["angle"], desc, np.zeros(nq, np.uint8), 15.0)
-                prev = (kps, desc)
-            tcpu = time.perf_counter() - tc
-            out["cpu_baseline"] = {"value": ns / tcpu, "unit": "frames/s", "cores": 1, "kind": "port",
-                                   "sample": "%d frames of the same synthetic stream through oracle/liborbref.so "
-                                             "(extract + %s match vs previous frame), 1 thread" % (ns, args.match),
-                                   "stage_ms_per_frame": {k: v / ns for k, v in ref.stage_ms().items()}}
-        print(json.dumps(out))
+        if stub:
+            out["metric"] = "stub (no GPU work): launcher / rendezvous / gather rehearsal"
+            out["config"] = {"workload": "stub", "frames_per_step_per_gpu": B, "keypoints_last_batch": total_kp}
+            print(json.dumps(out))
+        else:
+            out.update(report(wl, args, world, dt, dt_res, t_enq, gpu_wall, extra, total_kp, frames))
+            print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def report(wl, args, world, dt, dt_res, t_enq, gpu_wall, extra, total_kp, frames):
+    import numpy as np
+    import torch
+    ex, mt, B, W, H, nF = wl.ex, wl.mt, wl.B, wl.W, wl.H, wl.nF
+    L = wl.L
+    # per-stage breakdown: the same batch again, eagerly, with every stage event recorded (untimed)
+    L.orbx_set_stage_timing(ex.h, 1)
+    was_graph, wl.graph = wl.graph, False
+    for _ in range(max(3, min(8, args.steps))):
+        wl.step()
+    wl.sync()
+    wl.graph = was_graph
+    stage, _ = ex.mean_timings()
+    stage["pyramid_fast_span_staged"] = stage["pyramid_fast_span"]
+    stage["pyramid_fast_span"] = extra["span_ms"]; stage["total"] = extra["total_ms"]       # the live figures of the timed steps
+    stage["match"] = extra["match_ms"]
+    L.orbx_set_stage_timing(ex.h, 0)
+
+    alg, fused = ex.algorithmic_bytes()
+    # the blur's compulsory traffic is 2 * (sum of level pixels) = 2 * (alg - fused); it belongs to the pass when
+    # the blur is scheduled inside it (default: matrix-core blur behind the resize chain, beside FAST) -- the span then ends
+    # with the later of FAST and blur
+    blur_in = ex.blur_in_pass()
+    alg_pf = alg
+    if blur_in:
+        alg = alg + 2 * (alg - fused)
+    pf_ms = extra["span_ms"]
+    achieved = alg * B / (pf_ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None                  # HBM bytes per launch group from the committed rocprofv3 --pmc passes
+    for name in ("r02_traffic_%s.json" % wl.cfg, "r02_traffic.json", "r01_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            c = tj["config"]
+            if (c["width"], c["height"], c["nfeatures"]) == (W, H, nF):
+                traffic = (tj["pyramid_fast_bytes_per_frame"] + (tj["blur_bytes_per_frame"] if blur_in else 0)) * B
+                traffic_src = "profiles/" + name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per frame x frames per launch)"
+                break
+        except Exception:
+            continue
+    # secondary denominator: the device-to-device copy rate this GPU actually reaches, measured here with a
+    # 1 GiB torch copy (read + write bytes / time), outside the timed region
+    copy_gbs = None
+    try:
+        n = 1 << 30
+        a = torch.empty(n, dtype=torch.uint8, device="cuda"); b = torch.empty_like(a)
+        b.copy_(a); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b.copy_(a)
+        e1.record(); torch.cuda.synchronize()
+        copy_gbs = 2.0 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
+    except Exception:
+        copy_gbs = None
+    cw, ch, cnf, cb, _, cname = CONFIGS[wl.cfg]
+    named = (W, H, nF) == (cw, ch, cnf)
+    legs = {"c2": "dense 2-NN Hamming match (int8 MFMA) of every frame against the previous one",
+            "c5": "dense 2-NN Hamming match (int8 MFMA) of every frame against the previous one",
+            "c4": "%d fisheye stereo pairs: brute-force 2-NN of left x right descriptors per pair (ComputeStereoFishEyeMatches)" % (B // 2),
+            "c3": "%d stereo pairs: ComputeStereoMatches per pair + SearchForTriangulation against the previous pair" % (B // 2)}
+    if args.match == "window":
+        legs["c2"] = legs["c5"] = "Frame grid build and SearchByProjection window match (th=15) of every keypoint in the previous frame"
+    d2h = (28 + 32) * wl.cap * B + 8 * B
+    out = {
+        "metric": "ORB extract+match frames/sec @%dx%d, %d feat" % (W, H, nF),
+        "config": {"workload": (cname + ": " if named else "other size (not a named config): ") +
+                               "%dx%d grayscale, %d features, 8 levels, scale 1.2, FAST 20/7; batch of %d frames/GPU/step resident in HBM; "
+                               "extract + %s; keypoints, descriptors and counts of every batch copied to pinned host memory inside the timed region"
+                               % (W, H, nF, B, legs[wl.cfg]),
+                   "frames_per_step_per_gpu": B, "launch": "hipGraph replay (one hipGraphLaunch per step)" if wl.graph else "eager enqueue",
+                   "keypoints_last_batch": total_kp, "result_bytes_to_host_per_step": d2h},
+        "value_device_resident": frames / dt_res, "ms_per_step_device_resident": dt_res / args.steps * 1e3,
+        "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+        "gpu_wall_ms_per_step": gpu_wall / args.steps,
+        "gpu_total_ms_per_step": extra["total_ms"] + extra["match_ms"],
+        "roofline": {"bound": "hbm", "kernel": ("pyramid+FAST+blur pass (k_resize2 x7 then k_blur3 on stream 2 + k_fast3 x3 and k_fast_fix on stream 1; wall span by HIP events)"
+                                if blur_in else "pyramid+FAST pass (k_resize2 x7 on stream 2 + k_fast3 x3 and k_fast_fix on stream 1; wall span by HIP events)"),
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": alg * B, "frames_per_launch": B, "algorithmic_bytes_per_frame": alg,
+                     "fused_lower_bound_per_frame": fused, "launch_ms": pf_ms, "launch_samples": extra["nsamp"],
+                     "measured_copy_peak_GBps": copy_gbs,
+                     # for continuity with the pyramid+FAST-only figure: its own bytes over the span to the end of the last FAST
+                     # launch (stage events of the untimed staged pass; FAST is stretched by the blur running beside it)
+                     "pyramid_fast_only": ({"algorithmic_bytes_per_frame": alg_pf, "span_ms": stage["fast"],
+                                            "achieved": alg_pf * B / (stage["fast"] * 1e-3) / 1e9,
+                                            "frac": alg_pf * B / (stage["fast"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                           if blur_in and stage.get("fast", 0) > 0 else None),
+                     "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None},
+        "stage_ms_per_step": stage,
+    }
+    # host copy == device results (outside the timed region): one more step, then compare its pinned copy with per-frame fetches
+    wl.step()
+    wl.sync()
+    blk = (wl.k - 1) & 1
+    n_pin = wl.h_n[blk].view(np.int32, (B,)); m_pin = wl.h_mono[blk].view(np.int32, (B,))
+    k_pin = wl.h_kps[blk].view(np.uint8, (B, wl.cap, 28)); d_pin = wl.h_desc[blk].view(np.uint8, (B, wl.cap, 32))
+    ok = bool(np.array_equal(wl.counts(), n_pin))
+    for i in sorted({0, B // 2, B - 1}):
+        mono, kps, desc = ex.fetch(i)
+        n = len(kps)
+        ok = ok and n == int(n_pin[i]) and mono == int(m_pin[i]) and np.array_equal(kps.view(np.uint8).reshape(n, 28), k_pin[i, :n]) and np.array_equal(desc, d_pin[i, :n])
+    out["host_copy_matches_device"] = ok
+    if world == 1 and args.cpu_sample > 0:
+        out.update(cpu_baseline(wl, args))
+    return out
 
 
 if __name__ == "__main__":

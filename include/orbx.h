@@ -112,6 +112,35 @@ int orbx_stream_wait_other(orbx_t*, void* other_stream);
  * before its first kernel that writes the result block -- a matcher on its own stream then runs beside the next batch's
  * pyramid / FAST phase.  Call after enqueueing the reader's work and before the next orbx_extract_batch_async. */
 int orbx_guard_results(orbx_t*, void* reader_stream);
+/* HIP-graph replay of an enqueue sequence.  Between orbx_capture_begin(o, slot) and orbx_capture_end(o) every *_async /
+ * enqueue-only call on this handle -- orbx_extract_batch_async on device-resident 16-byte aligned images,
+ * orbx_result_download_async, the stream-ordering helpers, and matcher calls whose stream is the extractor's
+ * (orbm_set_stream(m, orbx_stream(o))) -- is recorded instead of run; orbx_graph_launch(o, slot) then replays the whole
+ * two-stream fork/join (plus the copy stream) with ONE runtime call.  The same batch (image pointers, size, lapping areas)
+ * must have been enqueued once eagerly before, so that geometry and per-frame tables are in place.  slot in [0, 8): every
+ * slot keeps its own time stamps -- a captured sequence marks start / end of FAST / end of blur / end of batch with a one-lane
+ * wall-clock kernel, because event records stamp nothing on replay -- and orbx_mean_timings averages the latest replay of each
+ * launched slot (total and pass span only; the per-stage figures need an eager batch).  A change of image
+ * size drops all graphs.  No allocation, host sync or host-image staging may happen inside a capture. */
+int orbx_capture_begin(orbx_t*, int slot);
+int orbx_capture_end(orbx_t*);
+int orbx_graph_launch(orbx_t*, int slot);
+/* results -> host (the reference's consumers read mvKeys / mDescriptors on the host, src/Frame.cc:357-366).  The handle owns
+ * TWO result blocks; a batch writes the current one (orbx_set_result_block, default 0; orbx_result_device / orbx_result_fetch*
+ * refer to it).  orbx_result_download_async copies the current block -- kps [nimg][cap], desc [nimg][cap][32], counts [nimg],
+ * monos [nimg]; NULL skips an array -- to PINNED host buffers (orbx_host_alloc) on the handle's copy stream, behind everything
+ * enqueued so far on the extractor's stream.  A caller that alternates the blocks batch by batch gets the copy of batch i beside
+ * the kernels of batch i+1; the next batch that rewrites a block waits (on the device) for that block's copy.  Enqueued eagerly,
+ * never inside a capture (a graph launch takes the wait for its block).  orbx_download_sync (or orbx_sync) waits for the copies. */
+int orbx_result_download_async(orbx_t*, orbx_kp_t* kps, uint8_t* desc, int32_t* counts, int32_t* monos, int nimg);
+int orbx_set_result_block(orbx_t*, int block);
+int orbx_download_sync(orbx_t*);
+/* two caller-placed time stamps on the extractor's stream (which = 0 / 1) and the time between them: the GPU-side wall time
+ * of a run of batches or graph replays, gaps included */
+int orbx_mark(orbx_t*, int which);
+int orbx_mark_elapsed_ms(orbx_t*, float* ms);
+void* orbx_host_alloc(size_t bytes);   /* pinned host memory */
+void orbx_host_free(void*);
 /* SURVEY 8(f).4 image ingest -- replaces cv::cvtColor(im, gray, COLOR_{RGB,BGR,RGBA,BGRA}2GRAY) in Tracking::GrabImage*
  * (src/Tracking.cc:1264-1290, 1339-1348, 1393-1402).  nimg interleaved 8-bit colour images (src_space = ORBX_HOST | ORBX_DEVICE)
  * are converted into the caller's DEVICE buffers dst[i] (dst_stride bytes per row; a multiple of 16 lets orbx_extract_batch*

@@ -29,6 +29,8 @@ EXPORTS = [
     "orbx_level_image", "orbx_scale_tables", "orbx_features_per_level", "orbx_level_candidates",
     "orbx_level_selected", "orbx_last_timings", "orbx_set_stage_timing", "orbx_mean_timings", "orbx_stream_wait_results", "orbx_stream_wait_other", "orbx_guard_results", "orbx_gray_from_color", "orbx_remap_linear", "orbx_clahe", "orbx_algorithmic_bytes", "orbx_blur_in_pass", "orbx_stream", "orbx_dev_alloc",
     "orbx_dev_free", "orbx_memcpy_h2d", "orbx_memcpy_d2h", "orbx_device_count",
+    "orbx_capture_begin", "orbx_capture_end", "orbx_graph_launch", "orbx_result_download_async", "orbx_download_sync",
+    "orbx_host_alloc", "orbx_host_free", "orbx_set_result_block", "orbx_mark", "orbx_mark_elapsed_ms",
     # include/orbm.h
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_sync", "orbm_stream", "orbm_set_stream", "orbm_hamming",
     "orbm_three_maxima", "orbm_knn2_batch", "orbm_knn2_batch_async", "orbm_last_timing",
@@ -89,6 +91,17 @@ def lib():
         L.orbx_dev_free.argtypes = [vp]
         L.orbx_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
         L.orbx_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
+        L.orbx_capture_begin.argtypes = [vp, ci]
+        L.orbx_capture_end.argtypes = [vp]
+        L.orbx_graph_launch.argtypes = [vp, ci]
+        L.orbx_result_download_async.argtypes = [vp, vp, vp, vp, vp, ci]
+        L.orbx_download_sync.argtypes = [vp]
+        L.orbx_set_result_block.argtypes = [vp, ci]
+        L.orbx_host_alloc.restype = vp
+        L.orbx_host_alloc.argtypes = [C.c_size_t]
+        L.orbx_host_free.argtypes = [vp]
+        L.orbx_mark.argtypes = [vp, ci]
+        L.orbx_mark_elapsed_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.orbm_create.argtypes = [C.POINTER(vp), ci]
         L.orbm_destroy.argtypes = [vp]
         L.orbm_last_error.restype = C.c_char_p
@@ -139,6 +152,28 @@ class DeviceBuffer:
     def __del__(self):
         try:
             lib().orbx_dev_free(self.ptr)
+        except Exception:
+            pass
+
+
+class PinnedBuffer:
+    """hipHostMalloc'd bytes with a numpy view (destination of orbx_result_download_async)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = lib().orbx_host_alloc(max(1, self.nbytes))
+        if not self.ptr:
+            raise OrbError("pinned allocation of %d bytes failed" % nbytes)
+        self.bytes = np.ctypeslib.as_array((C.c_uint8 * max(1, self.nbytes)).from_address(self.ptr))
+
+    def view(self, dtype, shape):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        return self.bytes[:n].view(dtype).reshape(shape)
+
+    def __del__(self):
+        try:
+            self.bytes = None
+            lib().orbx_host_free(self.ptr)
         except Exception:
             pass
 

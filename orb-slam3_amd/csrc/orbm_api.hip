@@ -36,6 +36,14 @@ struct orbm {
     size_t arCap = 0, arOff = 0, arUp = 0, arOutLo = (size_t)-1, arOutHi = 0;   // bump offset; [0, arUp) staged uploads; small outputs in [arOutLo, arOutHi)
 };
 
+// time stamps: under stream capture (the caller replays this enqueue sequence as a HIP graph, orbx_capture_begin) an event
+// record stamps nothing on replay, so it is skipped there: orbm_last_timing keeps reporting the last eagerly enqueued call
+static hipError_t rec_time(orbm* m, hipEvent_t ev) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(m->stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) return hipSuccess;
+    return hipEventRecord(ev, m->stream);
+}
+
 namespace { int knn2_host(orbm* m, const uint8_t* q, int q_stride, const int32_t* nq, const uint8_t* t, int t_stride, const int32_t* nt,
                           int npairs, int32_t* idx2, int32_t* dist2); }
 
@@ -116,14 +124,14 @@ int orbm_knn2_batch_async(orbm_t* m, const uint8_t* q, int q_stride, const int32
     if (t_stride >= (1 << 22)) { set_merr("knn2: more than 2^22 train descriptors per pair"); return ORBM_E_INVALID; }
     MHIPCHK(hipSetDevice(m->device));
     m->gridFirst = false;
-    MHIPCHK(hipEventRecord(m->e0, m->stream));
+    MHIPCHK(rec_time(m, m->e0));
     // matrix-core kernel unless the train set is beyond its 19-bit row field (or ORBM_KNN2_VALU asks for the popcount kernel: A/B)
     const bool forceValu = getenv("ORBM_KNN2_VALU") != nullptr;   // read per call: tests flip it
     if (t_stride <= KM_MAX_NT && !forceValu)
         hipLaunchKernelGGL(k_knn2_mfma, dim3((q_stride + 255) / 256, npairs), dim3(256), 0, m->stream, q, q_stride, nq, t, t_stride, nt, idx2, dist2);
     else
         hipLaunchKernelGGL(k_knn2, dim3((q_stride + 63) / 64, npairs), dim3(256), 0, m->stream, q, q_stride, nq, t, t_stride, nt, idx2, dist2);
-    MHIPCHK(hipEventRecord(m->e1, m->stream));
+    MHIPCHK(rec_time(m, m->e1));
     MHIPCHK(hipGetLastError());
     m->timed = true;
     return ORBM_OK;
@@ -262,14 +270,14 @@ int window_pass(orbm* m, const orbm_frame_t* f, int nq, const float* qx, const f
     AL_BIG(didx, sizeof(int) * (size_t)nq * cap); AL_BIG(ddist, sizeof(int) * (size_t)nq * cap);   // [nq][cap]: only the used columns come back
     AL_BIG(dpack, 2 * sizeof(int) * (size_t)nq * cap);       // packed copy of the used columns (reserved now: the arena must not grow after the launch)
     MHIPCHK(hipMemsetAsync(dovf.ptr(), 0, sizeof(int), m->stream));
-    MHIPCHK(hipEventRecord(m->e0, m->stream));
+    MHIPCHK(rec_time(m, m->e0));
     ARENA_FLUSH(m);
     hipLaunchKernelGGL(k_window, dim3((nq + 3) / 4), dim3(256), 0, m->stream, dk.as<KpIn>(), dd.as<uint8_t>(),
                        f->uright ? du.as<float>() : nullptr, dgs.as<int>(), dgi.as<int>(), f->min_x, f->min_y, f->inv_w, f->inv_h,
                        nq, dqx.as<float>(), dqy.as<float>(), dqr.as<float>(), dmin.as<int>(), dmax.as<int>(),
                        qur ? dqu.as<float>() : nullptr, qer ? dqe.as<float>() : nullptr, dqd.as<uint8_t>(), cap,
                        dcnt.as<int>(), didx.as<int>(), ddist.as<int>(), dovf.as<int>());
-    MHIPCHK(hipEventRecord(m->e1, m->stream));
+    MHIPCHK(rec_time(m, m->e1));
     m->timed = true;
     MHIPCHK(hipGetLastError());
     MHIPCHK(hipStreamSynchronize(m->stream));
@@ -310,11 +318,11 @@ int bucket_pass(orbm* m, const uint8_t* d1, int n1, const uint8_t* d2, int n2, c
     const int nj = (int)J.q.size();
     UP(bq, J.q.data(), sizeof(int) * nj); UP(bl, J.l2.data(), sizeof(int) * nj); UP(bo, J.off.data(), sizeof(int) * nj);
     AL(bout, sizeof(int) * (size_t)J.total);
-    MHIPCHK(hipEventRecord(m->e0, m->stream));
+    MHIPCHK(rec_time(m, m->e0));
     ARENA_FLUSH(m);
     hipLaunchKernelGGL(k_pairdist, dim3((J.total + 255) / 256), dim3(256), 0, m->stream, b1.as<uint8_t>(), b2.as<uint8_t>(),
                        bi.as<int>(), nj, bq.as<int>(), bl.as<int>(), bo.as<int>(), J.total, bout.as<int>());
-    MHIPCHK(hipEventRecord(m->e1, m->stream));
+    MHIPCHK(rec_time(m, m->e1));
     m->timed = true;
     MHIPCHK(hipGetLastError());
     MHIPCHK(hipStreamSynchronize(m->stream));
@@ -805,7 +813,7 @@ int orbm_grid_build_batch_async(orbm_t* m, const orbm_kp_t* kps, const int32_t* 
     int n2 = 64; while (n2 < cap) n2 <<= 1;
     if ((size_t)n2 * 4 > 150 * 1024) { set_merr("too many keypoints per frame for the LDS sort"); return ORBM_E_CAPACITY; }
     if (n2 * 4 > 48 * 1024) MHIPCHK(hipFuncSetAttribute((const void*)k_grid_build_batch, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 4));
-    MHIPCHK(hipEventRecord(m->e2, m->stream));
+    MHIPCHK(rec_time(m, m->e2));
     m->gridFirst = true;                                                    // orbm_last_timing then spans grid build + the next kernel
     hipLaunchKernelGGL(k_grid_build_batch, dim3(nframes), dim3(256), (size_t)n2 * 4, m->stream, (const KpIn*)kps, counts, cap, n2,
                        min_x, min_y, inv_w, inv_h, grid_start, grid_idx);
@@ -823,10 +831,10 @@ int orbm_track_window_batch_async(orbm_t* m, const orbm_kp_t* kps, const uint8_t
     MHIPCHK(hipSetDevice(m->device));
     ScaleTab st;
     for (int i = 0; i < 12; ++i) st.sf[i] = i < nlevels ? sf[i] : sf[nlevels - 1];
-    MHIPCHK(hipEventRecord(m->e0, m->stream));
+    MHIPCHK(rec_time(m, m->e0));
     hipLaunchKernelGGL(k_track_window, dim3((cap + 3) / 4, npairs), dim3(256), 0, m->stream, (const KpIn*)kps, desc, counts, cap,
                        grid_start, grid_idx, min_x, min_y, inv_w, inv_h, q_first, t_first, th, st, dx, dy, best_idx, best_dist, second_dist);
-    MHIPCHK(hipEventRecord(m->e1, m->stream));
+    MHIPCHK(rec_time(m, m->e1));
     MHIPCHK(hipGetLastError());
     m->timed = true;
     return ORBM_OK;
@@ -922,11 +930,11 @@ int orbm_bow_transform(orbm_t* m, const orbm_vocab_t* v, const uint8_t* desc, in
     arena_reset(m);
     UP(dd, desc, (size_t)32 * n); AL(dw, sizeof(int) * n); AL(dn, sizeof(int) * n); AL(dwt, sizeof(double) * n);
     m->gridFirst = false;
-    MHIPCHK(hipEventRecord(m->e0, m->stream));
+    MHIPCHK(rec_time(m, m->e0));
     ARENA_FLUSH(m);
     hipLaunchKernelGGL(k_bow_transform, dim3((n + 255) / 256), dim3(256), 0, m->stream, dd.as<uint8_t>(), n, v->dChildStart, v->dChildIdx,
                        v->dDesc, v->dWord, v->dWeight, v->L, levelsup, dw.as<int>(), dn.as<int>(), dwt.as<double>());
-    MHIPCHK(hipEventRecord(m->e1, m->stream));
+    MHIPCHK(rec_time(m, m->e1));
     m->timed = true;
     MHIPCHK(hipGetLastError());
     MHIPCHK(hipStreamSynchronize(m->stream));
@@ -1275,11 +1283,11 @@ int orbm_stereo_matches(orbm_t* m, void* left, int frame_l, void* right, int fra
     arena_reset(m);
     UP(bkl, kl, sizeof(KpIn) * nl); UP(bdl, dl, (size_t)32 * nl); UP(bkr, kr, sizeof(KpIn) * nr); UP(bdr, dr, (size_t)32 * nr);
     AL(bur, sizeof(float) * nl); AL(bde, sizeof(float) * nl); AL(bsad, sizeof(int) * nl);
-    MHIPCHK(hipEventRecord(m->e0, m->stream));
+    MHIPCHK(rec_time(m, m->e0));
     ARENA_FLUSH(m);
     hipLaunchKernelGGL(k_stereo, dim3((nl + 3) / 4), dim3(256), 0, m->stream, bkl.as<KpIn>(), bdl.as<uint8_t>(), nl, bkr.as<KpIn>(),
                        bdr.as<uint8_t>(), nr, lv, mb, mbf, bur.as<float>(), bde.as<float>(), bsad.as<int>());
-    MHIPCHK(hipEventRecord(m->e1, m->stream));
+    MHIPCHK(rec_time(m, m->e1));
     m->timed = true;
     MHIPCHK(hipGetLastError());
     MHIPCHK(hipStreamSynchronize(m->stream));

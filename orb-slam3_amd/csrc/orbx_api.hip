@@ -74,6 +74,23 @@ struct orbx {
     hipEvent_t* ev = evr[0];
     hipEvent_t evDone = nullptr;
     hipEvent_t evGuard = nullptr; bool guardPending = false;   // orbx_guard_results: a reader of the result block on another stream
+    // results -> host: copy stream + "copy may start" / "copy done" events (orbx_result_download_async)
+    hipStream_t stream3 = nullptr; hipEvent_t evDlStart = nullptr, evDl[2] = {}; bool dlPending[2] = {false, false};
+    // two result blocks (keypoints, descriptors, counts, mono indices): a batch writes the CURRENT one (orbx_set_result_block),
+    // so the copy of batch i's block to the host can run beside batch i+1, which writes the other block.  dKps / dDesc / dN /
+    // dMono below always alias the current block.
+    struct ResBlock { KpOut* kps = nullptr; u8* desc = nullptr; int *n = nullptr, *mono = nullptr; } rb[2];
+    int curBlock = 0;
+    // HIP-graph replay of an enqueue sequence (orbx_capture_begin / _end / orbx_graph_launch): per slot the instantiated graph
+    // and its own timing events (recorded as external event nodes, so a replay refreshes them)
+    struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int nimg = 0, block = 0; long launches = 0; };
+    unsigned long long* dStamps = nullptr; int wallClockKHz = 0;   // k_stamp slots [kSlots][4]
+    static const int kSlots = 8;
+    GraphSlot gs[kSlots];
+    int capSlot = -1;                                          // >= 0 while the streams are being captured
+    bool graphMode = false;                                    // the most recent batch came from a graph replay
+    hipEvent_t evDepc[12] = {};                                // capture mode: dependency twins of the timing events
+    hipEvent_t evMark[2] = {};                                 // orbx_mark: caller-placed time stamps on the extractor's stream
     long nEnq = 0;
     u8 *dPyr = nullptr, *dBlur = nullptr, *dL0 = nullptr;
     const u8** dL0Ptr = nullptr;
@@ -117,6 +134,18 @@ template <class T> static int ensure(T** p, size_t* cap, size_t need) {
 static int build_geometry(orbx* o, int w, int h) {
     if (o->curW == w && o->curH == h) return 0;
     if (w > o->maxW || h > o->maxH) { set_err("image %dx%d exceeds the configured maximum %dx%d", w, h, o->maxW, o->maxH); return ORBX_E_CAPACITY; }
+    if (o->capSlot >= 0) { set_err("the image size must not change while a graph is being captured"); return ORBX_E_INVALID; }
+    // Everything below tears the current geometry down before it can fail (too small / unsupported / out of memory): mark the
+    // handle as having NO geometry first, so that a failed rebuild can never be mistaken for a valid one by the next call
+    // with the previous size, and nothing refers to freed result buffers.
+    o->curW = o->curH = 0; o->lastBatch = 0; o->countsValid = false; o->timed = false; o->graphMode = false;
+    if (o->stream) { (void)hipStreamSynchronize(o->stream); (void)hipStreamSynchronize(o->stream2); (void)hipStreamSynchronize(o->stream3); }
+    for (auto& G : o->gs) {                                    // graphs captured for the old geometry hold its pointers and grids
+        if (G.exec) (void)hipGraphExecDestroy(G.exec);
+        if (G.graph) (void)hipGraphDestroy(G.graph);
+        G.exec = nullptr; G.graph = nullptr; G.launches = 0; G.nimg = 0;
+    }
+    o->upPtr.clear(); o->upLap.clear();
     Geom& g = o->g;
     memset(&g, 0, sizeof g);
     const int L = o->nlevels;
@@ -363,10 +392,14 @@ static int build_geometry(orbx* o, int w, int h) {
     { size_t c2 = 0; if (o->dDense) (void)hipFree(o->dDense); o->dDense = nullptr; if (ensure(&o->dDense, &c2, (size_t)g.totalSlots * B)) return ORBX_E_HIP; }
     if (ensure(&o->dSel, &o->capSel, (size_t)g.totalSel * B)) return ORBX_E_HIP;
     {
-        if (o->dKps) (void)hipFree(o->dKps); if (o->dDesc) (void)hipFree(o->dDesc); if (o->dWork) (void)hipFree(o->dWork);
+        for (auto& R : o->rb) { if (R.kps) (void)hipFree(R.kps); if (R.desc) (void)hipFree(R.desc); R.kps = nullptr; R.desc = nullptr; }
+        if (o->dWork) (void)hipFree(o->dWork);
         o->dKps = nullptr; o->dDesc = nullptr; o->dWork = nullptr;
-        HIPCHK(hipMalloc((void**)&o->dKps, sizeof(KpOut) * g.kpCap * B));
-        HIPCHK(hipMalloc((void**)&o->dDesc, (size_t)32 * g.kpCap * B));
+        for (auto& R : o->rb) {
+            HIPCHK(hipMalloc((void**)&R.kps, sizeof(KpOut) * g.kpCap * B));
+            HIPCHK(hipMalloc((void**)&R.desc, (size_t)32 * g.kpCap * B));
+        }
+        o->dKps = o->rb[o->curBlock].kps; o->dDesc = o->rb[o->curBlock].desc;
         HIPCHK(hipMalloc((void**)&o->dWork, sizeof(KpWork) * g.kpCap * B));
     }
     HIPCHK(hipMemcpy(o->dCells, o->cells.data(), o->cells.size() * sizeof(CellInfo), hipMemcpyHostToDevice));
@@ -426,7 +459,19 @@ static int build_geometry(orbx* o, int w, int h) {
 }
 
 // stage-boundary events exist only for the per-stage timings; the dependency / span events (0, 2, 6, 8, 9) are always recorded
-#define STAGE_EV(i, stream) do { if (o->stageTiming) HIPCHK(hipEventRecord(o->ev[i], stream)); } while (0)
+// Eager mode: one HIP event serves as time stamp and as dependency.  Under stream capture an event record is only a dependency
+// marker -- nothing is stamped on replay (external event-record nodes would be, but the HIP 7.0 runtime that PyTorch ships and
+// that bench.py therefore runs on rejects hipEventRecordExternal) -- so a captured sequence marks the four span boundaries
+// (start, end of FAST, end of blur, end of batch) with k_stamp and takes its dependencies from twin events.
+static hipError_t rec_ev(orbx* o, int i, hipStream_t s, bool dep) {
+    if (o->capSlot < 0) return hipEventRecord(o->ev[i], s);
+    const int k = i == 0 ? 0 : i == 2 ? 1 : i == 9 ? 2 : i == 6 ? 3 : -1;
+    if (k >= 0) hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, s, o->dStamps + (size_t)o->capSlot * 4 + k);
+    if (!dep) return hipSuccess;
+    return hipEventRecord(o->evDepc[i], s);
+}
+static inline hipEvent_t dep_ev(orbx* o, int i) { return o->capSlot < 0 ? o->ev[i] : o->evDepc[i]; }
+#define STAGE_EV(i, stream) do { if (o->stageTiming && o->capSlot < 0) HIPCHK(hipEventRecord(o->ev[i], stream)); } while (0)
 
 extern "C" {
 
@@ -488,10 +533,16 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
         for (auto& e : o->evLvl) if (rc == ORBX_OK && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
         if (rc == ORBX_OK && hipEventCreateWithFlags(&o->evDone, hipEventDisableTiming) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
         if (rc == ORBX_OK && hipEventCreateWithFlags(&o->evGuard, hipEventDisableTiming) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
+        if (rc == ORBX_OK && (hipStreamCreateWithFlags(&o->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&o->evDlStart, hipEventDisableTiming) != hipSuccess ||
+                              hipEventCreateWithFlags(&o->evDl[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&o->evDl[1], hipEventDisableTiming) != hipSuccess)) { rc = ORBX_E_HIP; set_err("copy stream creation failed"); }
+        for (auto& e : o->evDepc) if (rc == ORBX_OK && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
+        if (rc == ORBX_OK && (hipMalloc((void**)&o->dStamps, sizeof(unsigned long long) * orbx::kSlots * 4) != hipSuccess ||
+                              hipDeviceGetAttribute(&o->wallClockKHz, hipDeviceAttributeWallClockRate, device_id) != hipSuccess || o->wallClockKHz <= 0)) { rc = ORBX_E_HIP; set_err("time stamp setup failed"); }
         if (rc) break;
         const size_t B = max_batch;
         if (hipMalloc((void**)&o->dL0Ptr, sizeof(u8*) * B) != hipSuccess || hipMalloc((void**)&o->dSelCnt, sizeof(u32) * 12 * B) != hipSuccess ||
-            hipMalloc((void**)&o->dN, sizeof(int) * B) != hipSuccess || hipMalloc((void**)&o->dMono, sizeof(int) * B) != hipSuccess ||
+            hipMalloc((void**)&o->rb[0].n, sizeof(int) * B) != hipSuccess || hipMalloc((void**)&o->rb[0].mono, sizeof(int) * B) != hipSuccess ||
+            hipMalloc((void**)&o->rb[1].n, sizeof(int) * B) != hipSuccess || hipMalloc((void**)&o->rb[1].mono, sizeof(int) * B) != hipSuccess ||
             hipMalloc((void**)&o->dLap, sizeof(int) * 2 * B) != hipSuccess || hipMalloc((void**)&o->dErr, sizeof(int)) != hipSuccess ||
             hipMalloc((void**)&o->dPattern, 1024) != hipSuccess || hipMalloc((void**)&o->dOdW, sizeof(u32) * OD_WTAB) != hipSuccess || hipMalloc((void**)&o->dOvf, 2 * sizeof(u32)) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
         {   // IC_Angle weights for v_dot4: entry [|v|][j] packs, for the 4 bytes of dword j of a 32-byte patch row (it starts at
@@ -511,6 +562,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
         }
         if (hipMemcpy(o->dPattern, kPattern, 1024, hipMemcpyHostToDevice) != hipSuccess || hipMemset(o->dErr, 0, sizeof(int)) != hipSuccess || hipMemset(o->dOvf, 0, 2 * sizeof(u32)) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMemcpy failed"); break; }
         o->hL0Ptr.resize(B); o->hLap.resize(2 * B);
+        o->dN = o->rb[0].n; o->dMono = o->rb[0].mono;
         rc = build_geometry(o, max_w, max_h);
     } while (0);
     if (rc) { orbx_destroy(o); return rc; }
@@ -523,8 +575,18 @@ void orbx_destroy(orbx_t* o) {
     (void)hipSetDevice(o->device);
     if (o->stream) (void)hipStreamSynchronize(o->stream);
     if (o->stream2) (void)hipStreamSynchronize(o->stream2);
+    if (o->stream3) (void)hipStreamSynchronize(o->stream3);
+    for (auto& G : o->gs) {
+        if (G.exec) (void)hipGraphExecDestroy(G.exec);
+        if (G.graph) (void)hipGraphDestroy(G.graph);
+    }
+    for (auto& e : o->evDepc) if (e) (void)hipEventDestroy(e);
+    for (auto& e : o->evMark) if (e) (void)hipEventDestroy(e);
+    if (o->evDlStart) (void)hipEventDestroy(o->evDlStart);
+    for (auto& e : o->evDl) if (e) (void)hipEventDestroy(e);
+    if (o->stream3) (void)hipStreamDestroy(o->stream3);
     void* ptrs[] = {o->dPyr, o->dBlur, o->dL0, (void*)o->dL0Ptr, o->dCells, o->dTiles, o->dTiles3, o->dB3Th, o->dB3Tv, o->dStrips, o->dX4, o->dRzTasks, o->dXt, o->dYt, o->dCandCnt, o->dCandEnt,
-                    o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->dKps, o->dDesc, o->dWork, o->dN, o->dMono, o->dLap, o->dErr, o->dPattern, o->dOvf, o->dOvfList, o->dOdW};
+                    o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->rb[0].kps, o->rb[0].desc, o->rb[1].kps, o->rb[1].desc, o->dWork, o->rb[0].n, o->rb[0].mono, o->rb[1].n, o->rb[1].mono, o->dLap, o->dErr, o->dPattern, o->dOvf, o->dOvfList, o->dOdW, (void*)o->dStamps};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& set : o->evr) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     if (o->evDone) (void)hipEventDestroy(o->evDone);
@@ -552,9 +614,13 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     if (rc) return rc;
     const Geom& g = o->g;
     hipStream_t st = o->stream;
+    const bool capturing = o->capSlot >= 0;
     int l0pitch;
     bool aligned = (stride % 16) == 0;
     for (int i = 0; i < nimg && aligned; ++i) aligned = ((uintptr_t)imgs[i] % 16) == 0;
+    if (capturing && !(img_space == ORBX_DEVICE && aligned)) {
+        set_err("graph capture takes device-resident, 16-byte aligned images only (staging copies are per-call host work)"); return ORBX_E_INVALID;
+    }
     if (img_space == ORBX_DEVICE && aligned) {
         for (int i = 0; i < nimg; ++i) o->hL0Ptr[i] = imgs[i];
         l0pitch = stride;
@@ -590,6 +656,10 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     for (int i = 0; i < nimg; ++i) { o->hLap[2 * i] = lap01 ? lap01[2 * i] : 0; o->hLap[2 * i + 1] = lap01 ? lap01[2 * i + 1] : 0; }
     // the per-frame pointer and lapping tables are re-uploaded only when they change (a streaming caller cycling through
     // the same device buffers pays for them once: two tiny copies cost ~25 us of stream time per batch)
+    if (capturing && (o->upPtr.size() != (size_t)nimg || memcmp(o->upPtr.data(), o->hL0Ptr.data(), sizeof(u8*) * nimg) != 0 ||
+                      o->upLap.size() != (size_t)(2 * nimg) || memcmp(o->upLap.data(), o->hLap.data(), sizeof(int) * 2 * nimg) != 0)) {
+        set_err("graph capture: enqueue the same batch (same image pointers and lapping areas) once outside the capture first"); return ORBX_E_INVALID;
+    }
     if (o->upPtr.size() != (size_t)nimg || memcmp(o->upPtr.data(), o->hL0Ptr.data(), sizeof(u8*) * nimg) != 0) {
         HIPCHK(hipMemcpyAsync((void*)o->dL0Ptr, o->hL0Ptr.data(), sizeof(u8*) * nimg, hipMemcpyHostToDevice, st));
         o->upPtr.assign(o->hL0Ptr.begin(), o->hL0Ptr.begin() + nimg);
@@ -600,15 +670,14 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     }
 
     o->lastL0Pitch = l0pitch;
-    o->ev = o->evr[o->nEnq % orbx::kRing];
-    ++o->nEnq;
+    if (!capturing) { o->ev = o->evr[o->nEnq % orbx::kRing]; ++o->nEnq; }
     // Two HIP streams (events order them): FAST is VALU-bound, the resize chain is latency-bound and the quadtree is
     // LDS-latency-bound -- so level-0 FAST (needs no resize) runs beside the resize chain and the blur beside the quadtree.
     //   s0: FAST(L0) --wait pyramid--> FAST(L1..) -> quadtree -> slots --wait blur--> orientation+descriptors
     //   s1: resize L1..L7 -> [pyramid ready] --wait FAST--> blur -> [blur ready]
     hipStream_t s1 = o->serial ? o->stream : o->stream2;          // ORBX_SERIAL=1: single stream, clean per-kernel timings
-    HIPCHK(hipEventRecord(o->ev[0], st));
-    HIPCHK(hipStreamWaitEvent(s1, o->ev[0], 0));                 // inputs uploaded; previous batch's readers of the pyramid are done
+    HIPCHK(rec_ev(o, 0, st, true));
+    HIPCHK(hipStreamWaitEvent(s1, dep_ev(o, 0), 0));             // inputs uploaded; previous batch's readers of the pyramid are done
     STAGE_EV(7, s1);
     for (int l = 1; l < g.nlevels; ++l) {
         if (o->rzStream[l]) {
@@ -622,9 +691,9 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
         if (!o->fastV1 && l < g.nlevels - 1)
             for (const orbx::F3Group& G : o->f3g) if (G.lastLevel == l) HIPCHK(hipEventRecord(o->evLvl[l], s1));
     }
-    HIPCHK(hipEventRecord(o->ev[8], s1));                        // pyramid ready
+    HIPCHK(rec_ev(o, 8, s1, true));                              // pyramid ready
     if (o->fastV1) {
-        HIPCHK(hipStreamWaitEvent(st, o->ev[8], 0));
+        HIPCHK(hipStreamWaitEvent(st, dep_ev(o, 8), 0));
         STAGE_EV(1, st);
         hipLaunchKernelGGL(k_fast, dim3(g.totalCells, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dCells,
                            o->dCandCnt, o->dCandEnt, o->dErr);
@@ -637,7 +706,7 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
             const bool lvl0 = G.lastLevel == 0;
             if (!lvl0) {
                 if (first) STAGE_EV(10, st);   // level-0 FAST done
-                HIPCHK(hipStreamWaitEvent(st, G.lastLevel < g.nlevels - 1 ? o->evLvl[G.lastLevel] : o->ev[8], 0));
+                HIPCHK(hipStreamWaitEvent(st, G.lastLevel < g.nlevels - 1 ? o->evLvl[G.lastLevel] : dep_ev(o, 8), 0));
                 if (first) STAGE_EV(1, st);
                 first = false;
             }
@@ -648,13 +717,13 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
             STAGE_EV(10, st);
             STAGE_EV(1, st);
         }
-        HIPCHK(hipStreamWaitEvent(st, o->ev[8], 0));             // later stages read every level
+        HIPCHK(hipStreamWaitEvent(st, dep_ev(o, 8), 0));         // later stages read every level
         hipLaunchKernelGGL(k_fast_fix, dim3(512), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dCells, o->dCandCnt, o->dCandEnt,
                            o->dErr, o->dOvf, o->dOvfList);
     }
-    HIPCHK(hipEventRecord(o->ev[2], st));
+    HIPCHK(rec_ev(o, 2, st, true));
     // blur (VALU + HBM) runs beside the quadtree (LDS-latency bound), not beside FAST (VALU bound)
-    if (!o->serial && !o->blurEarly) HIPCHK(hipStreamWaitEvent(s1, o->ev[2], 0));
+    if (!o->serial && !o->blurEarly) HIPCHK(hipStreamWaitEvent(s1, dep_ev(o, 2), 0));
     STAGE_EV(11, s1);
     if (o->blurV2)
         hipLaunchKernelGGL(k_blur2, dim3((unsigned)(o->tiles.size() + 3) / 4, nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
@@ -667,7 +736,7 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
         hipLaunchKernelGGL(k_blur3, dim3((unsigned)count, nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
                            o->dTiles3 + first, (const uint4*)o->dB3Th, (const uint4*)o->dB3Tv);
     }
-    HIPCHK(hipEventRecord(o->ev[9], s1));                        // blur ready
+    HIPCHK(rec_ev(o, 9, s1, true));                              // blur ready
     if (o->qtV1)
         hipLaunchKernelGGL(k_quadtree, dim3(nimg, g.nlevels), dim3(256), o->qtLds, st, g, o->dCells, o->dCandCnt, o->dCandEnt,
                            o->dKpNode, o->dSel, o->dSelCnt, o->dErr);
@@ -685,9 +754,13 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
         HIPCHK(hipStreamWaitEvent(st, o->evGuard, 0));
         o->guardPending = false;
     }
+    if (!capturing && o->dlPending[o->curBlock]) {               // ... and this block's previous contents may still be on their way to the host
+        HIPCHK(hipStreamWaitEvent(st, o->evDl[o->curBlock], 0));    // (a graph replay takes this wait in orbx_graph_launch)
+        o->dlPending[o->curBlock] = false;
+    }
     hipLaunchKernelGGL(k_slots, dim3(nimg), dim3(256), 0, st, g, o->dSel, o->dSelCnt, o->dLap, o->dKps, o->dWork, o->dN, o->dMono);
     STAGE_EV(4, st);
-    HIPCHK(hipStreamWaitEvent(st, o->ev[9], 0));
+    HIPCHK(hipStreamWaitEvent(st, dep_ev(o, 9), 0));
     STAGE_EV(5, st);
     if (o->odV1)
         hipLaunchKernelGGL(k_orient_desc, dim3((g.kpCap + 3) / 4, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
@@ -695,19 +768,134 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     else
         hipLaunchKernelGGL(k_orient_desc2, dim3((g.kpCap + 15) / 16, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
                            o->dWork, o->dN, o->dKps, o->dDesc, o->dPattern, o->dOdW);
-    HIPCHK(hipEventRecord(o->ev[6], st));
+    HIPCHK(rec_ev(o, 6, st, false));
     HIPCHK(hipGetLastError());
+    if (capturing) { o->gs[o->capSlot].nimg = nimg; o->gs[o->capSlot].block = o->curBlock; return ORBX_OK; }   // nothing has run: the handle's state changes at orbx_graph_launch
     o->lastBatch = nimg;
     o->timed = true;
+    o->graphMode = false;
     o->countsValid = false;
     return ORBX_OK;
 }
+
+// ---- HIP-graph replay.  Between orbx_capture_begin and orbx_capture_end every *_async call on this handle (and on anything
+// whose stream is the extractor's: orbm_set_stream(m, orbx_stream(o))) is recorded instead of run -- the two-stream fork/join
+// of the extraction, the match kernels behind it, the results-to-host copies on the copy stream -- and one orbx_graph_launch
+// replays the lot with a single runtime call.
+int orbx_capture_begin(orbx_t* o, int slot) {
+    if (!o || slot < 0 || slot >= orbx::kSlots) return ORBX_E_INVALID;
+    if (o->capSlot >= 0) { set_err("a capture is already open"); return ORBX_E_INVALID; }
+    if (!o->curW) { set_err("run one batch eagerly first: capture needs the geometry and the per-frame tables in place"); return ORBX_E_INVALID; }
+    HIPCHK(hipSetDevice(o->device));
+    HIPCHK(hipStreamSynchronize(o->stream)); HIPCHK(hipStreamSynchronize(o->stream2)); HIPCHK(hipStreamSynchronize(o->stream3));
+    orbx::GraphSlot& G = o->gs[slot];
+    if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
+    if (G.graph) { (void)hipGraphDestroy(G.graph); G.graph = nullptr; }
+    G.launches = 0; G.nimg = 0;
+    HIPCHK(hipStreamBeginCapture(o->stream, hipStreamCaptureModeThreadLocal));
+    o->capSlot = slot;
+    return ORBX_OK;
+}
+
+int orbx_capture_end(orbx_t* o) {
+    if (!o || o->capSlot < 0) return ORBX_E_INVALID;
+    orbx::GraphSlot& G = o->gs[o->capSlot];
+    hipStream_t st = o->stream;
+    // forked streams must be joined before the capture ends: a download enqueued behind the last batch has no consumer yet
+    hipError_t e = hipSuccess;
+    if (o->guardPending) { e = hipStreamWaitEvent(st, o->evGuard, 0); o->guardPending = false; }
+    o->capSlot = -1;
+    hipGraph_t graph = nullptr;
+    hipError_t e2 = hipStreamEndCapture(st, &graph);
+    if (e != hipSuccess || e2 != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        set_err("stream capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        return ORBX_E_HIP;
+    }
+    G.graph = graph;
+    HIPCHK(hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0));
+    return ORBX_OK;
+}
+
+int orbx_graph_launch(orbx_t* o, int slot) {
+    if (!o || slot < 0 || slot >= orbx::kSlots || !o->gs[slot].exec || o->capSlot >= 0) return ORBX_E_INVALID;
+    orbx::GraphSlot& G = o->gs[slot];
+    if (G.nimg > 0 && o->dlPending[G.block]) {                   // the block this graph rewrites may still be on its way to the host
+        HIPCHK(hipStreamWaitEvent(o->stream, o->evDl[G.block], 0));
+        o->dlPending[G.block] = false;
+    }
+    HIPCHK(hipGraphLaunch(G.exec, o->stream));
+    ++G.launches;
+    if (G.nimg > 0) { const int rc = orbx_set_result_block(o, G.block); if (rc) return rc; }
+    if (G.nimg > 0) { o->lastBatch = G.nimg; o->countsValid = false; o->timed = true; o->graphMode = true; }
+    return ORBX_OK;
+}
+
+// ---- results -> host.  The reference's consumers are host-side (Frame.cc:357-366 fills mvKeys / mDescriptors), so SURVEY 8(d)
+// counts this copy in the metric.  The copy runs on its own stream behind everything enqueued so far on the extractor's stream,
+// i.e. beside the NEXT batch's pyramid / FAST phase; that batch waits for it only before its first kernel that rewrites the
+// result block.  Destinations should be pinned (orbx_host_alloc) -- pageable memory makes the copy synchronous.
+int orbx_result_download_async(orbx_t* o, orbx_kp_t* kps, uint8_t* desc, int32_t* counts, int32_t* monos, int nimg) {
+    if (!o || nimg < 1 || nimg > o->maxBatch || !o->curW) return ORBX_E_INVALID;
+    if (o->capSlot >= 0) { set_err("the copy to the host is enqueued eagerly, behind the graph launch, not captured"); return ORBX_E_INVALID; }
+    HIPCHK(hipSetDevice(o->device));
+    const size_t dc = (size_t)o->g.kpCap;
+    HIPCHK(hipEventRecord(o->evDlStart, o->stream));
+    HIPCHK(hipStreamWaitEvent(o->stream3, o->evDlStart, 0));
+    if (kps) HIPCHK(hipMemcpyAsync(kps, o->dKps, sizeof(KpOut) * dc * nimg, hipMemcpyDeviceToHost, o->stream3));
+    if (desc) HIPCHK(hipMemcpyAsync(desc, o->dDesc, 32 * dc * nimg, hipMemcpyDeviceToHost, o->stream3));
+    if (counts) HIPCHK(hipMemcpyAsync(counts, o->dN, sizeof(int) * (size_t)nimg, hipMemcpyDeviceToHost, o->stream3));
+    if (monos) HIPCHK(hipMemcpyAsync(monos, o->dMono, sizeof(int) * (size_t)nimg, hipMemcpyDeviceToHost, o->stream3));
+    HIPCHK(hipEventRecord(o->evDl[o->curBlock], o->stream3));
+    o->dlPending[o->curBlock] = true;
+    return ORBX_OK;
+}
+
+int orbx_set_result_block(orbx_t* o, int block) {
+    if (!o || block < 0 || block > 1) return ORBX_E_INVALID;
+    if (block != o->curBlock) o->countsValid = false;
+    o->curBlock = block;
+    o->dKps = o->rb[block].kps; o->dDesc = o->rb[block].desc; o->dN = o->rb[block].n; o->dMono = o->rb[block].mono;
+    return ORBX_OK;
+}
+
+int orbx_download_sync(orbx_t* o) {
+    if (!o) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    HIPCHK(hipStreamSynchronize(o->stream3));
+    return ORBX_OK;
+}
+
+// caller-placed time stamps on the extractor's stream (which = 0 / 1), e.g. around a run of graph replays: the GPU-side wall
+// time of the whole run, gaps between batches included
+int orbx_mark(orbx_t* o, int which) {
+    if (!o || which < 0 || which > 1 || o->capSlot >= 0) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    if (!o->evMark[which]) HIPCHK(hipEventCreate(&o->evMark[which]));
+    HIPCHK(hipEventRecord(o->evMark[which], o->stream));
+    return ORBX_OK;
+}
+int orbx_mark_elapsed_ms(orbx_t* o, float* ms) {
+    if (!o || !ms || !o->evMark[0] || !o->evMark[1]) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    HIPCHK(hipEventSynchronize(o->evMark[1]));
+    HIPCHK(hipEventElapsedTime(ms, o->evMark[0], o->evMark[1]));
+    return ORBX_OK;
+}
+
+void* orbx_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { set_err("hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+void orbx_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 int orbx_sync(orbx_t* o) {
     if (!o) return ORBX_E_INVALID;
     HIPCHK(hipSetDevice(o->device));
     HIPCHK(hipStreamSynchronize(o->stream));
     HIPCHK(hipStreamSynchronize(o->stream2));
+    HIPCHK(hipStreamSynchronize(o->stream3));
     int e = 0;
     HIPCHK(hipMemcpy(&e, o->dErr, sizeof(int), hipMemcpyDeviceToHost));
     if (e) { set_err("device-side overflow flag %d", e); (void)hipMemset(o->dErr, 0, sizeof(int)); return ORBX_E_INTERNAL; }
@@ -905,6 +1093,7 @@ int orbx_last_timings(orbx_t* o, float* ms7) {   // 8 floats, see include/orbx.h
     HIPCHK(hipSetDevice(o->device));
     HIPCHK(hipStreamSynchronize(o->stream));
     HIPCHK(hipStreamSynchronize(o->stream2));
+    if (o->graphMode) return orbx_mean_timings(o, ms7, nullptr);
     return timings_of(o, o->ev, ms7);
 }
 
@@ -913,13 +1102,30 @@ int orbx_mean_timings(orbx_t* o, float* ms8, int* nsamples) {
     HIPCHK(hipSetDevice(o->device));
     HIPCHK(hipStreamSynchronize(o->stream));
     HIPCHK(hipStreamSynchronize(o->stream2));
-    const int n = (int)std::min<long>(o->nEnq, orbx::kRing);
+    int n = 0;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < n; ++k) {
-        float t[8];
-        int rc = timings_of(o, o->evr[(o->nEnq - 1 - k) % orbx::kRing], t);
-        if (rc) return rc;
-        for (int i = 0; i < 8; ++i) acc[i] += t[i];
+    if (o->graphMode) {                                      // replays refresh their slot's own stamps: the latest replay of every slot
+        unsigned long long st[orbx::kSlots * 4];
+        HIPCHK(hipMemcpy(st, o->dStamps, sizeof st, hipMemcpyDeviceToHost));
+        const double msPerTick = 1.0 / (double)o->wallClockKHz;
+        for (int k = 0; k < orbx::kSlots; ++k) {
+            const orbx::GraphSlot& G = o->gs[k];
+            if (!G.exec || G.launches < 1 || G.nimg < 1) continue;
+            const unsigned long long* t = st + 4 * k;
+            unsigned long long passEnd = t[1];
+            if (o->blurEarly && !o->serial && t[2] > passEnd) passEnd = t[2];
+            acc[6] += (double)(t[3] - t[0]) * msPerTick;
+            acc[7] += (double)(passEnd - t[0]) * msPerTick;
+            ++n;
+        }
+    } else {
+        n = (int)std::min<long>(o->nEnq, orbx::kRing);
+        for (int k = 0; k < n; ++k) {
+            float t[8];
+            int rc = timings_of(o, o->evr[(o->nEnq - 1 - k) % orbx::kRing], t);
+            if (rc) return rc;
+            for (int i = 0; i < 8; ++i) acc[i] += t[i];
+        }
     }
     for (int i = 0; i < 8; ++i) ms8[i] = n ? (float)(acc[i] / n) : 0.f;
     if (nsamples) *nsamples = n;

@@ -1757,6 +1757,13 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
 // RGB2Gray<uchar>, gray = (c0*C0 + c1*GY + c2*C2 + half) >> bits.  One thread makes 4 gray pixels (one dword store) from 12 /
 // 16 source bytes fetched as dwords when the row allows it.  Pure streaming: 4 or 5 bytes of HBM traffic per pixel.
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------------
+// time stamp (graph replays): HIP events recorded during stream capture stamp nothing on replay (and the runtime PyTorch
+// ships rejects hipEventRecordExternal), so a captured sequence marks its span boundaries with this one-lane kernel instead:
+// the constant-rate wall clock (hipDeviceAttributeWallClockRate, 100 MHz on gfx950) at the point of the stream it sits on
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void k_stamp(unsigned long long* p) { *p = (unsigned long long)wall_clock64(); }
+
 __global__ __launch_bounds__(256) void k_gray(const u8* const* srcs, int w, int h, int sstride, int ch,
                                               int c0, int gy, int c2, int bits, u8* const* dsts, int dstride) {
     const int frame = blockIdx.z;
