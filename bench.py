@@ -70,22 +70,39 @@ def parse_args(argv=None):
 # launcher: `python bench.py --gpus N` outside torchrun starts N fresh rank processes (nothing GPU-related has been imported here)
 # ----------------------------------------------------------------------------------------------------------------------
 def launch_ranks(n, argv):
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    # a rank that dies takes the job down: the others would wait for it in the rendezvous or in a collective
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()                       # exactly the children started above
+            break
+        time.sleep(0.1)
+    rcs = []
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=30))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(p.wait())
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        sys.stderr.write("bench.py: ranks failed: %s\n" % bad)
+    if failed or any(rc != 0 for rc in rcs):
+        sys.stderr.write("bench.py: ranks failed, exit codes %s\n" % rcs)
         return 1
     return 0
 
@@ -100,6 +117,8 @@ class StubWorkload:
     def __init__(self, args, rank, local_rank):
         self.B = args.batch or 4
         self.rank = rank
+        if os.environ.get("ORB_BENCH_STUB_FAIL_RANK") == str(rank):      # launcher test: a rank that dies before the rendezvous
+            raise SystemExit(3)
 
     def prime(self):
         pass
@@ -168,8 +187,8 @@ class OrbWorkload:
             self.sf_host = ex.GetScaleFactors()
             self.inv_w = float(np.float32(64) / np.float32(W)); self.inv_h = float(np.float32(48) / np.float32(H))   # Frame.cc:401-402
         # ---- where the results land on the host: pinned, one block per array (reused every step, like a Frame's mvKeys)
-        self.h_kps = [pkg.PinnedBuffer(28 * cap * B) for _ in (0, 1)]; self.h_desc = [pkg.PinnedBuffer(32 * cap * B) for _ in (0, 1)]
-        self.h_n = [pkg.PinnedBuffer(4 * B) for _ in (0, 1)]; self.h_mono = [pkg.PinnedBuffer(4 * B) for _ in (0, 1)]
+        self.layout = ex.result_block_layout()                  # one block = [kps | desc | counts | monos], moved by ONE copy
+        self.h_blk = [pkg.PinnedBuffer(self.layout[4]) for _ in (0, 1)]
         self.download = True
         self.graph = args.launch == "graph" and args.match == "knn2"
         self.nslots = 4
@@ -242,7 +261,7 @@ class OrbWorkload:
         else:
             self._enqueue(blk)
         if self.download:
-            rc = self.L.orbx_result_download_async(self.ex.h, self.h_kps[blk].ptr, self.h_desc[blk].ptr, self.h_n[blk].ptr, self.h_mono[blk].ptr, self.B)
+            rc = self.L.orbx_result_download_async(self.ex.h, self.h_blk[blk].ptr)
             assert rc == 0, rc
         self.k += 1
 
@@ -516,7 +535,7 @@ def report(wl, args, world, dt, dt_res, t_enq, gpu_wall, extra, total_kp, frames
             "c3": "%d stereo pairs: ComputeStereoMatches per pair + SearchForTriangulation against the previous pair" % (B // 2)}
     if args.match == "window":
         legs["c2"] = legs["c5"] = "Frame grid build and SearchByProjection window match (th=15) of every keypoint in the previous frame"
-    d2h = (28 + 32) * wl.cap * B + 8 * B
+    d2h = wl.layout[4]
     out = {
         "metric": "ORB extract+match frames/sec @%dx%d, %d feat" % (W, H, nF),
         "config": {"workload": (cname + ": " if named else "other size (not a named config): ") +
@@ -549,8 +568,10 @@ def report(wl, args, world, dt, dt_res, t_enq, gpu_wall, extra, total_kp, frames
     wl.step()
     wl.sync()
     blk = (wl.k - 1) & 1
-    n_pin = wl.h_n[blk].view(np.int32, (B,)); m_pin = wl.h_mono[blk].view(np.int32, (B,))
-    k_pin = wl.h_kps[blk].view(np.uint8, (B, wl.cap, 28)); d_pin = wl.h_desc[blk].view(np.uint8, (B, wl.cap, 32))
+    ok_, od_, on_, om_, _ = wl.layout
+    hb = wl.h_blk[blk].bytes
+    n_pin = hb[on_:on_ + 4 * B].view(np.int32); m_pin = hb[om_:om_ + 4 * B].view(np.int32)
+    k_pin = hb[ok_:ok_ + 28 * wl.cap * B].reshape(B, wl.cap, 28); d_pin = hb[od_:od_ + 32 * wl.cap * B].reshape(B, wl.cap, 32)
     ok = bool(np.array_equal(wl.counts(), n_pin))
     for i in sorted({0, B // 2, B - 1}):
         mono, kps, desc = ex.fetch(i)

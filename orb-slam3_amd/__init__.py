@@ -29,7 +29,7 @@ EXPORTS = [
     "orbx_level_image", "orbx_scale_tables", "orbx_features_per_level", "orbx_level_candidates",
     "orbx_level_selected", "orbx_last_timings", "orbx_set_stage_timing", "orbx_mean_timings", "orbx_stream_wait_results", "orbx_stream_wait_other", "orbx_guard_results", "orbx_gray_from_color", "orbx_remap_linear", "orbx_clahe", "orbx_algorithmic_bytes", "orbx_blur_in_pass", "orbx_stream", "orbx_dev_alloc",
     "orbx_dev_free", "orbx_memcpy_h2d", "orbx_memcpy_d2h", "orbx_device_count",
-    "orbx_capture_begin", "orbx_capture_end", "orbx_graph_launch", "orbx_result_download_async", "orbx_download_sync",
+    "orbx_capture_begin", "orbx_capture_end", "orbx_graph_launch", "orbx_result_download_async", "orbx_result_block_layout", "orbx_download_sync",
     "orbx_host_alloc", "orbx_host_free", "orbx_set_result_block", "orbx_mark", "orbx_mark_elapsed_ms",
     # include/orbm.h
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_sync", "orbm_stream", "orbm_set_stream", "orbm_hamming",
@@ -94,7 +94,8 @@ def lib():
         L.orbx_capture_begin.argtypes = [vp, ci]
         L.orbx_capture_end.argtypes = [vp]
         L.orbx_graph_launch.argtypes = [vp, ci]
-        L.orbx_result_download_async.argtypes = [vp, vp, vp, vp, vp, ci]
+        L.orbx_result_download_async.argtypes = [vp, vp]
+        L.orbx_result_block_layout.argtypes = [vp] + [C.POINTER(C.c_size_t)] * 5
         L.orbx_download_sync.argtypes = [vp]
         L.orbx_set_result_block.argtypes = [vp, ci]
         L.orbx_host_alloc.restype = vp
@@ -337,6 +338,12 @@ class ORBextractor:
         mono = C.c_int32(0)
         n = _chk(self.L.orbx_result_fetch(self.h, i, _p(kps), _p(desc), self.cap, C.byref(mono)), "orbx_result_fetch")
         return mono.value, kps[:n].copy(), desc[:n].copy()
+
+    def result_block_layout(self):
+        """(off_kps, off_desc, off_counts, off_monos, bytes) of a result block (include/orbx.h: orbx_result_block_layout)."""
+        v = [C.c_size_t() for _ in range(5)]
+        _chk(self.L.orbx_result_block_layout(self.h, *[C.byref(x) for x in v]), "result_block_layout")
+        return tuple(int(x.value) for x in v)
 
     def result_device(self):
         k, d, c, m = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()

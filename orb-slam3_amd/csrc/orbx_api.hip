@@ -79,8 +79,12 @@ struct orbx {
     // two result blocks (keypoints, descriptors, counts, mono indices): a batch writes the CURRENT one (orbx_set_result_block),
     // so the copy of batch i's block to the host can run beside batch i+1, which writes the other block.  dKps / dDesc / dN /
     // dMono below always alias the current block.
-    struct ResBlock { KpOut* kps = nullptr; u8* desc = nullptr; int *n = nullptr, *mono = nullptr; } rb[2];
+    // A block is ONE allocation -- [kps | desc | counts | monos] at offKps.. -- so that it reaches the host with a single copy
+    // (several back-to-back hipMemcpyAsync on one stream block the calling thread for ~0.4 ms each on this runtime).
+    struct ResBlock { u8* base = nullptr; KpOut* kps = nullptr; u8* desc = nullptr; int *n = nullptr, *mono = nullptr; } rb[2];
+    size_t offKps = 0, offDesc = 0, offN = 0, offMono = 0, blockBytes = 0;
     int curBlock = 0;
+    bool dlMemcpy = false; int dlGrid = 64;                    // ORBX_DL_MEMCPY / ORBX_DL_GRID: A/B switches of the results-to-host copy
     // HIP-graph replay of an enqueue sequence (orbx_capture_begin / _end / orbx_graph_launch): per slot the instantiated graph
     // and its own timing events (recorded as external event nodes, so a replay refreshes them)
     struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int nimg = 0, block = 0; long launches = 0; };
@@ -120,6 +124,8 @@ struct orbx {
     std::vector<int> hLap;
     bool timed = false;
 };
+
+extern "C" int orbx_set_result_block(orbx_t* o, int block);
 
 template <class T> static int ensure(T** p, size_t* cap, size_t need) {
     if (need <= *cap && *p) return 0;
@@ -392,14 +398,20 @@ static int build_geometry(orbx* o, int w, int h) {
     { size_t c2 = 0; if (o->dDense) (void)hipFree(o->dDense); o->dDense = nullptr; if (ensure(&o->dDense, &c2, (size_t)g.totalSlots * B)) return ORBX_E_HIP; }
     if (ensure(&o->dSel, &o->capSel, (size_t)g.totalSel * B)) return ORBX_E_HIP;
     {
-        for (auto& R : o->rb) { if (R.kps) (void)hipFree(R.kps); if (R.desc) (void)hipFree(R.desc); R.kps = nullptr; R.desc = nullptr; }
+        for (auto& R : o->rb) { if (R.base) (void)hipFree(R.base); R = orbx::ResBlock(); }
         if (o->dWork) (void)hipFree(o->dWork);
-        o->dKps = nullptr; o->dDesc = nullptr; o->dWork = nullptr;
+        o->dKps = nullptr; o->dDesc = nullptr; o->dN = nullptr; o->dMono = nullptr; o->dWork = nullptr;
+        o->offKps = 0;
+        o->offDesc = (sizeof(KpOut) * g.kpCap * B + 255) & ~(size_t)255;
+        o->offN = o->offDesc + (((size_t)32 * g.kpCap * B + 255) & ~(size_t)255);
+        o->offMono = o->offN + ((sizeof(int) * B + 255) & ~(size_t)255);
+        o->blockBytes = o->offMono + ((sizeof(int) * B + 255) & ~(size_t)255);
         for (auto& R : o->rb) {
-            HIPCHK(hipMalloc((void**)&R.kps, sizeof(KpOut) * g.kpCap * B));
-            HIPCHK(hipMalloc((void**)&R.desc, (size_t)32 * g.kpCap * B));
+            HIPCHK(hipMalloc((void**)&R.base, o->blockBytes));
+            HIPCHK(hipMemset(R.base, 0, o->blockBytes));
+            R.kps = (KpOut*)(R.base + o->offKps); R.desc = R.base + o->offDesc; R.n = (int*)(R.base + o->offN); R.mono = (int*)(R.base + o->offMono);
         }
-        o->dKps = o->rb[o->curBlock].kps; o->dDesc = o->rb[o->curBlock].desc;
+        (void)orbx_set_result_block(o, o->curBlock);
         HIPCHK(hipMalloc((void**)&o->dWork, sizeof(KpWork) * g.kpCap * B));
     }
     HIPCHK(hipMemcpy(o->dCells, o->cells.data(), o->cells.size() * sizeof(CellInfo), hipMemcpyHostToDevice));
@@ -508,6 +520,8 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     if (const char* e = getenv("ORBX_FAST_QCAP")) o->f3QcapForce = atoi(e);
     if (const char* e = getenv("ORBX_QT_WIDE")) o->qtWideForce = atoi(e) != 0 ? 1 : 0;
     o->blurEarly = !o->blurV2 && getenv("ORBX_BLUR_LATE") == nullptr;
+    o->dlMemcpy = getenv("ORBX_DL_MEMCPY") != nullptr;
+    if (const char* e = getenv("ORBX_DL_GRID")) o->dlGrid = std::max(1, atoi(e));
     o->serial = getenv("ORBX_SERIAL") != nullptr;            // A/B switch: simple per-cell reference kernel
     o->scaleFactor = scale_factor;                              // double member initialised from float (ORBextractor.h:96)
     const int L = nlevels;
@@ -541,8 +555,6 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
         if (rc) break;
         const size_t B = max_batch;
         if (hipMalloc((void**)&o->dL0Ptr, sizeof(u8*) * B) != hipSuccess || hipMalloc((void**)&o->dSelCnt, sizeof(u32) * 12 * B) != hipSuccess ||
-            hipMalloc((void**)&o->rb[0].n, sizeof(int) * B) != hipSuccess || hipMalloc((void**)&o->rb[0].mono, sizeof(int) * B) != hipSuccess ||
-            hipMalloc((void**)&o->rb[1].n, sizeof(int) * B) != hipSuccess || hipMalloc((void**)&o->rb[1].mono, sizeof(int) * B) != hipSuccess ||
             hipMalloc((void**)&o->dLap, sizeof(int) * 2 * B) != hipSuccess || hipMalloc((void**)&o->dErr, sizeof(int)) != hipSuccess ||
             hipMalloc((void**)&o->dPattern, 1024) != hipSuccess || hipMalloc((void**)&o->dOdW, sizeof(u32) * OD_WTAB) != hipSuccess || hipMalloc((void**)&o->dOvf, 2 * sizeof(u32)) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMalloc failed"); break; }
         {   // IC_Angle weights for v_dot4: entry [|v|][j] packs, for the 4 bytes of dword j of a 32-byte patch row (it starts at
@@ -562,7 +574,6 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
         }
         if (hipMemcpy(o->dPattern, kPattern, 1024, hipMemcpyHostToDevice) != hipSuccess || hipMemset(o->dErr, 0, sizeof(int)) != hipSuccess || hipMemset(o->dOvf, 0, 2 * sizeof(u32)) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipMemcpy failed"); break; }
         o->hL0Ptr.resize(B); o->hLap.resize(2 * B);
-        o->dN = o->rb[0].n; o->dMono = o->rb[0].mono;
         rc = build_geometry(o, max_w, max_h);
     } while (0);
     if (rc) { orbx_destroy(o); return rc; }
@@ -586,7 +597,7 @@ void orbx_destroy(orbx_t* o) {
     for (auto& e : o->evDl) if (e) (void)hipEventDestroy(e);
     if (o->stream3) (void)hipStreamDestroy(o->stream3);
     void* ptrs[] = {o->dPyr, o->dBlur, o->dL0, (void*)o->dL0Ptr, o->dCells, o->dTiles, o->dTiles3, o->dB3Th, o->dB3Tv, o->dStrips, o->dX4, o->dRzTasks, o->dXt, o->dYt, o->dCandCnt, o->dCandEnt,
-                    o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->rb[0].kps, o->rb[0].desc, o->rb[1].kps, o->rb[1].desc, o->dWork, o->rb[0].n, o->rb[0].mono, o->rb[1].n, o->rb[1].mono, o->dLap, o->dErr, o->dPattern, o->dOvf, o->dOvfList, o->dOdW, (void*)o->dStamps};
+                    o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->rb[0].base, o->rb[1].base, o->dWork, o->dLap, o->dErr, o->dPattern, o->dOvf, o->dOvfList, o->dOdW, (void*)o->dStamps};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& set : o->evr) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     if (o->evDone) (void)hipEventDestroy(o->evDone);
@@ -835,19 +846,31 @@ int orbx_graph_launch(orbx_t* o, int slot) {
 // counts this copy in the metric.  The copy runs on its own stream behind everything enqueued so far on the extractor's stream,
 // i.e. beside the NEXT batch's pyramid / FAST phase; that batch waits for it only before its first kernel that rewrites the
 // result block.  Destinations should be pinned (orbx_host_alloc) -- pageable memory makes the copy synchronous.
-int orbx_result_download_async(orbx_t* o, orbx_kp_t* kps, uint8_t* desc, int32_t* counts, int32_t* monos, int nimg) {
-    if (!o || nimg < 1 || nimg > o->maxBatch || !o->curW) return ORBX_E_INVALID;
+int orbx_result_download_async(orbx_t* o, void* host_block) {
+    if (!o || !host_block || !o->curW) return ORBX_E_INVALID;
     if (o->capSlot >= 0) { set_err("the copy to the host is enqueued eagerly, behind the graph launch, not captured"); return ORBX_E_INVALID; }
     HIPCHK(hipSetDevice(o->device));
-    const size_t dc = (size_t)o->g.kpCap;
     HIPCHK(hipEventRecord(o->evDlStart, o->stream));
     HIPCHK(hipStreamWaitEvent(o->stream3, o->evDlStart, 0));
-    if (kps) HIPCHK(hipMemcpyAsync(kps, o->dKps, sizeof(KpOut) * dc * nimg, hipMemcpyDeviceToHost, o->stream3));
-    if (desc) HIPCHK(hipMemcpyAsync(desc, o->dDesc, 32 * dc * nimg, hipMemcpyDeviceToHost, o->stream3));
-    if (counts) HIPCHK(hipMemcpyAsync(counts, o->dN, sizeof(int) * (size_t)nimg, hipMemcpyDeviceToHost, o->stream3));
-    if (monos) HIPCHK(hipMemcpyAsync(monos, o->dMono, sizeof(int) * (size_t)nimg, hipMemcpyDeviceToHost, o->stream3));
+    if (o->dlMemcpy)
+        HIPCHK(hipMemcpyAsync(host_block, o->rb[o->curBlock].base, o->blockBytes, hipMemcpyDeviceToHost, o->stream3));
+    else {
+        const size_t n16 = o->blockBytes / 16;                   // blockBytes is a multiple of 256
+        const unsigned grid = (unsigned)std::min<size_t>(o->dlGrid, (n16 + 255) / 256);
+        hipLaunchKernelGGL(k_copy_out, dim3(grid), dim3(256), 0, o->stream3, (v4u_t*)host_block, (const v4u_t*)o->rb[o->curBlock].base, n16);
+    }
     HIPCHK(hipEventRecord(o->evDl[o->curBlock], o->stream3));
     o->dlPending[o->curBlock] = true;
+    return ORBX_OK;
+}
+
+int orbx_result_block_layout(const orbx_t* o, size_t* off_kps, size_t* off_desc, size_t* off_counts, size_t* off_monos, size_t* bytes) {
+    if (!o || !o->curW) return ORBX_E_INVALID;
+    if (off_kps) *off_kps = o->offKps;
+    if (off_desc) *off_desc = o->offDesc;
+    if (off_counts) *off_counts = o->offN;
+    if (off_monos) *off_monos = o->offMono;
+    if (bytes) *bytes = o->blockBytes;
     return ORBX_OK;
 }
 

@@ -1762,6 +1762,15 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
 // ships rejects hipEventRecordExternal), so a captured sequence marks its span boundaries with this one-lane kernel instead:
 // the constant-rate wall clock (hipDeviceAttributeWallClockRate, 100 MHz on gfx950) at the point of the stream it sits on
 // ------------------------------------------------------------------------------------------------------------------
+// results -> pinned host memory, written by the GPU itself (posted PCIe writes, 16 bytes per lane): a plain kernel launch on the
+// copy stream.  hipMemcpyAsync does the same job through the runtime's copy path, whose calls stall the enqueueing thread for
+// several milliseconds every ~10 copies on the runtime bench.py runs on; a launch does not.  A few workgroups saturate the link.
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy_out(v4u_t* __restrict__ dst, const v4u_t* __restrict__ src, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
 __global__ void k_stamp(unsigned long long* p) { *p = (unsigned long long)wall_clock64(); }
 
 __global__ __launch_bounds__(256) void k_gray(const u8* const* srcs, int w, int h, int sstride, int ch,

@@ -53,3 +53,34 @@ def test_shard_is_a_partition():
         for w in (1, 2, 4, 8):
             allf = sorted(sum((d.shard_frames(n, r, w) for r in range(w)), []))
             assert allf == list(range(n))
+
+
+def test_bench_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` outside torchrun spawns 2 fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*),
+    which rendezvous (gloo here), take the max-over-ranks time and gather the per-frame counts; rank 0 prints the one JSON
+    line with n_gpus = 2.  ORB_BENCH_STUB=1 swaps the GPU workload for a sleep, so this runs without a GPU."""
+    import json
+    import subprocess
+    env = dict(os.environ, ORB_BENCH_STUB="1", ORB_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "5"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["frames_per_step_per_gpu"] == 5
+    assert d["config"]["keypoints_last_batch"] == 5 * 1000 + 5 * 1001        # both ranks' counts arrived
+    assert abs(d["value"] - 2 * 5 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]   # whole-job frames / max-over-ranks time
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    import subprocess
+    env = dict(os.environ, ORB_BENCH_STUB="1", ORB_BENCH_BACKEND="gloo", ORB_BENCH_STUB_FAIL_RANK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0

@@ -249,3 +249,108 @@ def test_result_fetch_all_layouts(pkg, oracle, synth):
         assert ex.L.orbx_result_fetch_all(ex.h, None, None, 10, None, None) < 0      # 10 keypoints per frame are not enough
     finally:
         ex.close()
+
+
+def test_failed_geometry_rebuild_leaves_no_stale_state(pkg, oracle, synth):
+    """A call that fails while the geometry is being rebuilt (too small / too large an image) must not leave the handle looking
+    as if the previous size were still set up: the next valid call rebuilds everything and is bit-exact again."""
+    ex = pkg.ORBextractor(1000, max_size=(752, 480), max_batch=1)
+    img = synth.gen_image(752, 480, 21)
+    n_ref, kps_ref, desc_ref, mono_ref = oracle.Extractor(1000)(img, (0, 1000))
+    for bad in (synth.gen_image(40, 40, 1), synth.gen_image(120, 100, 1)):
+        mono, kps, desc = ex(img, (0, 1000))
+        assert mono == mono_ref and kps.tobytes() == kps_ref.tobytes() and np.array_equal(desc, desc_ref)
+        with pytest.raises(pkg.OrbError):
+            ex(bad)                                               # ORBX_E_TOO_SMALL after the old geometry is torn down
+        with pytest.raises(pkg.OrbError):
+            ex.fetch(0)                                           # nothing valid to fetch (no dangling result pointers)
+    mono, kps, desc = ex(img, (0, 1000))
+    assert mono == mono_ref and len(kps) == n_ref and kps.tobytes() == kps_ref.tobytes() and np.array_equal(desc, desc_ref)
+    ex.close()
+
+
+def _device_batch(pkg, synth, w, h, n, seed0):
+    import ctypes as C
+    stride = (w + 63) // 64 * 64
+    imgs = [synth.gen_image(w, h, seed0 + i) for i in range(n)]
+    dev = pkg.DeviceBuffer(n * stride * h)
+    for i, im in enumerate(imgs):
+        pad = np.zeros((h, stride), np.uint8); pad[:, :w] = im
+        dev.upload(pad, offset=i * stride * h)
+    arr = (C.c_void_p * n)(*[dev.ptr + i * stride * h for i in range(n)])
+    return imgs, dev, arr, stride
+
+
+def test_graph_replay_and_result_blocks_bit_exact(pkg, oracle, synth):
+    """bench.py's timed loop in small: the step (extraction into result block k & 1 + the dense match) captured into HIP
+    graphs and replayed, the block copied to a pinned host block of the same layout on the copy stream beside the next step.
+    Every replay's host copy must equal the eager results and the oracle, bit for bit; the replay timings must be sane."""
+    import ctypes as C
+    w, h, n = 421, 307, 5
+    imgs, dev, arr, stride = _device_batch(pkg, synth, w, h, n, 70)
+    L = pkg.lib()
+    ex = pkg.ORBextractor(600, max_size=(w, h), max_batch=n)
+    mt = pkg.ORBmatcher(0.7)
+    assert L.orbm_set_stream(mt.h, L.orbx_stream(ex.h)) == 0
+    cap = ex.cap
+    ref = oracle.Extractor(600)
+    want = [ref(im, (0, 0)) for im in imgs]
+    offk, offd, offn, offm, nbytes = ex.result_block_layout()
+    host = [pkg.PinnedBuffer(nbytes) for _ in (0, 1)]
+    idx2 = pkg.DeviceBuffer(n * cap * 8); dist2 = pkg.DeviceBuffer(n * cap * 8)
+    res = []
+    for blk in (0, 1):
+        assert L.orbx_set_result_block(ex.h, blk) == 0
+        res.append(ex.result_device())
+
+    def enqueue(blk):
+        assert L.orbx_set_result_block(ex.h, blk) == 0
+        ex.enqueue_device(arr, w, h, stride)
+        r = res[blk]
+        assert L.orbm_knn2_batch_async(mt.h, r["desc"] + cap * 32, cap, r["counts"] + 4, r["desc"], cap, r["counts"], n - 1, cap,
+                                       idx2.ptr + cap * 8, dist2.ptr + cap * 8) == 0
+
+    assert L.orbx_capture_begin(ex.h, 0) < 0                     # nothing has run eagerly yet -> refused... geometry exists, tables do not
+    enqueue(0); enqueue(1)
+    ex.sync()
+    for slot in range(4):
+        assert L.orbx_capture_begin(ex.h, slot) == 0, L.orbx_last_error()
+        assert L.orbx_result_download_async(ex.h, host[0].ptr) < 0      # the copy is never part of a capture
+        enqueue(slot & 1)
+        assert L.orbx_capture_end(ex.h) == 0, L.orbx_last_error()
+
+    def check_block(blk):
+        hb = host[blk].bytes
+        cnt = hb[offn:offn + 4 * n].view(np.int32); mono = hb[offm:offm + 4 * n].view(np.int32)
+        kp = hb[offk:offk + 28 * cap * n].reshape(n, cap, 28); de = hb[offd:offd + 32 * cap * n].reshape(n, cap, 32)
+        for i in range(n):
+            n_ref, kps_ref, desc_ref, mono_ref = want[i]
+            assert cnt[i] == n_ref and mono[i] == mono_ref, (blk, i)
+            assert kp[i, :n_ref].tobytes() == kps_ref.tobytes() and np.array_equal(de[i, :n_ref], desc_ref), (blk, i)
+
+    for k in range(10):                                          # replays, host never waits inside the loop
+        assert L.orbx_graph_launch(ex.h, k % 4) == 0, L.orbx_last_error()
+        assert L.orbx_result_download_async(ex.h, host[k & 1].ptr) == 0
+    ex.sync()
+    check_block(0); check_block(1)
+    for b in host:
+        b.bytes[:] = 0
+    assert L.orbx_graph_launch(ex.h, 1) == 0                     # a single replay into block 1, fetched through the ordinary path too
+    assert L.orbx_result_download_async(ex.h, host[1].ptr) == 0
+    ex.sync()
+    check_block(1)
+    for i in range(n):
+        mono, kps, desc = ex.fetch(i)
+        assert kps.tobytes() == want[i][1].tobytes() and np.array_equal(desc, want[i][2])
+    # match results of the replay == the eager host-array call
+    got_i = idx2.download(np.int32, n * cap * 2).reshape(n, cap, 2); got_d = dist2.download(np.int32, n * cap * 2).reshape(n, cap, 2)
+    for i in range(1, n):
+        wi, wd = oracle.knn2(want[i][2], want[i - 1][2])
+        nq = want[i][0]
+        assert np.array_equal(got_i[i, :nq], wi) and np.array_equal(got_d[i, :nq], wd)
+    tm, ns = ex.mean_timings()
+    assert ns >= 1 and 0 < tm["pyramid_fast_span"] <= tm["total"] < 50
+    # a new image size drops the graphs (they hold the old geometry)
+    ex(synth.gen_image(400, 300, 1))
+    assert L.orbx_graph_launch(ex.h, 0) < 0
+    ex.close(); mt.close()
