@@ -126,14 +126,15 @@ int orbx_capture_begin(orbx_t*, int slot);
 int orbx_capture_end(orbx_t*);
 int orbx_graph_launch(orbx_t*, int slot);
 /* results -> host (the reference's consumers read mvKeys / mDescriptors on the host, src/Frame.cc:357-366).  The handle owns
- * TWO result blocks; a batch writes the current one (orbx_set_result_block, default 0; orbx_result_device / orbx_result_fetch*
- * refer to it).  A block is one allocation holding kps [max_batch][cap], desc [max_batch][cap][32], counts [max_batch] and
- * monos [max_batch] at the byte offsets orbx_result_block_layout reports (they change with the image size).
- * orbx_result_download_async copies the current block with ONE transfer into a PINNED host block of the same layout
- * (orbx_host_alloc(bytes)) on the handle's copy stream, behind everything enqueued so far on the extractor's stream.  A
- * caller that alternates the blocks batch by batch gets the copy of batch i beside the kernels of batch i+1; the next batch
- * that rewrites a block waits (on the device) for that block's copy.  Enqueued eagerly, never inside a capture (a graph
- * launch takes the wait for its block).  orbx_download_sync (or orbx_sync) waits for the copies. */
+ * a ring of FOUR result blocks; a batch writes the current one (orbx_set_result_block(o, 0..3), default 0; orbx_result_device /
+ * orbx_result_fetch* refer to it).  A block is one allocation holding kps [max_batch][cap], desc [max_batch][cap][32],
+ * counts [max_batch] and monos [max_batch] at the byte offsets orbx_result_block_layout reports (they change with the image
+ * size).  orbx_result_download_async hands the current block to the handle's copy thread: it waits for the batch that fills
+ * the block, moves it with ONE transfer (copy engine, copy stream) into a PINNED host block of the same layout
+ * (orbx_host_alloc(bytes)) and marks the block free again.  The call itself returns at once; a caller that walks the ring batch
+ * by batch gets the copy of batch i beside the kernels of batch i+1.  Whoever is about to rewrite a block whose copy has not
+ * landed -- orbx_extract_batch_async, orbx_graph_launch, another download of the same block -- waits for it on the host first.
+ * Never inside a capture.  orbx_download_sync (or orbx_sync) returns when every requested copy has landed. */
 int orbx_result_block_layout(const orbx_t*, size_t* off_kps, size_t* off_desc, size_t* off_counts, size_t* off_monos, size_t* bytes);
 int orbx_result_download_async(orbx_t*, void* host_block);
 int orbx_set_result_block(orbx_t*, int block);

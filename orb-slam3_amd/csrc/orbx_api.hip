@@ -11,6 +11,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -75,16 +79,27 @@ struct orbx {
     hipEvent_t evDone = nullptr;
     hipEvent_t evGuard = nullptr; bool guardPending = false;   // orbx_guard_results: a reader of the result block on another stream
     // results -> host: copy stream + "copy may start" / "copy done" events (orbx_result_download_async)
-    hipStream_t stream3 = nullptr; hipEvent_t evDlStart = nullptr, evDl[2] = {}; bool dlPending[2] = {false, false};
-    // two result blocks (keypoints, descriptors, counts, mono indices): a batch writes the CURRENT one (orbx_set_result_block),
-    // so the copy of batch i's block to the host can run beside batch i+1, which writes the other block.  dKps / dDesc / dN /
-    // dMono below always alias the current block.
+    // results -> host: a ring of result blocks (keypoints, descriptors, counts, mono indices).  A batch writes the CURRENT block
+    // (orbx_set_result_block), so the copy of batch i's block to the host runs beside batch i+1, which writes another block.
+    // dKps / dDesc / dN / dMono below always alias the current block.
+    // The copies are issued by a helper thread: it waits (on the host) for the batch that fills the block, then starts a
+    // DEPENDENCY-FREE hipMemcpyAsync on the copy stream.  A copy that the runtime has to order behind unfinished kernels
+    // (hipStreamWaitEvent + hipMemcpyAsync) stalls the enqueueing thread for ~7 ms every ten or so calls on the HIP 7.0
+    // runtime bench.py runs on (tools/d2h_probe.py), which would starve the GPU whenever it hits the thread that launches
+    // the batches; a copy kernel has no such stalls but its PCIe writes slow the bandwidth-bound kernels beside it by 5-20 %.
+    // Flow control is host-side: a block is `busy` from orbx_result_download_async until its copy has landed, and whoever is
+    // about to rewrite a busy block (orbx_extract_batch_async / orbx_graph_launch) waits for it first.
+    static const int kBlocks = 4;
+    hipStream_t stream3 = nullptr;
+    hipEvent_t evBatchDone[kBlocks] = {};
+    std::thread dlThread; std::mutex dlMu; std::condition_variable dlCv;
+    struct DlReq { int block; void* host; };
+    std::deque<DlReq> dlQueue; bool dlBusy[kBlocks] = {}; bool dlStop = false; int dlError = 0; bool dlKernel = false; int dlGrid = 16;
     // A block is ONE allocation -- [kps | desc | counts | monos] at offKps.. -- so that it reaches the host with a single copy
     // (several back-to-back hipMemcpyAsync on one stream block the calling thread for ~0.4 ms each on this runtime).
-    struct ResBlock { u8* base = nullptr; KpOut* kps = nullptr; u8* desc = nullptr; int *n = nullptr, *mono = nullptr; } rb[2];
+    struct ResBlock { u8* base = nullptr; KpOut* kps = nullptr; u8* desc = nullptr; int *n = nullptr, *mono = nullptr; } rb[kBlocks];
     size_t offKps = 0, offDesc = 0, offN = 0, offMono = 0, blockBytes = 0;
     int curBlock = 0;
-    bool dlMemcpy = false; int dlGrid = 64;                    // ORBX_DL_MEMCPY / ORBX_DL_GRID: A/B switches of the results-to-host copy
     // HIP-graph replay of an enqueue sequence (orbx_capture_begin / _end / orbx_graph_launch): per slot the instantiated graph
     // and its own timing events (recorded as external event nodes, so a replay refreshes them)
     struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int nimg = 0, block = 0; long launches = 0; };
@@ -92,6 +107,7 @@ struct orbx {
     static const int kSlots = 8;
     GraphSlot gs[kSlots];
     int capSlot = -1;                                          // >= 0 while the streams are being captured
+    bool capFailed = false;                                    // an enqueue failed inside the open capture
     bool graphMode = false;                                    // the most recent batch came from a graph replay
     hipEvent_t evDepc[12] = {};                                // capture mode: dependency twins of the timing events
     hipEvent_t evMark[2] = {};                                 // orbx_mark: caller-placed time stamps on the extractor's stream
@@ -126,6 +142,8 @@ struct orbx {
 };
 
 extern "C" int orbx_set_result_block(orbx_t* o, int block);
+static int dl_drain(orbx* o);
+static int dl_wait_block(orbx* o, int b);
 
 template <class T> static int ensure(T** p, size_t* cap, size_t need) {
     if (need <= *cap && *p) return 0;
@@ -145,7 +163,7 @@ static int build_geometry(orbx* o, int w, int h) {
     // handle as having NO geometry first, so that a failed rebuild can never be mistaken for a valid one by the next call
     // with the previous size, and nothing refers to freed result buffers.
     o->curW = o->curH = 0; o->lastBatch = 0; o->countsValid = false; o->timed = false; o->graphMode = false;
-    if (o->stream) { (void)hipStreamSynchronize(o->stream); (void)hipStreamSynchronize(o->stream2); (void)hipStreamSynchronize(o->stream3); }
+    if (o->stream) { (void)hipStreamSynchronize(o->stream); (void)hipStreamSynchronize(o->stream2); (void)dl_drain(o); }
     for (auto& G : o->gs) {                                    // graphs captured for the old geometry hold its pointers and grids
         if (G.exec) (void)hipGraphExecDestroy(G.exec);
         if (G.graph) (void)hipGraphDestroy(G.graph);
@@ -485,6 +503,56 @@ static hipError_t rec_ev(orbx* o, int i, hipStream_t s, bool dep) {
 static inline hipEvent_t dep_ev(orbx* o, int i) { return o->capSlot < 0 ? o->ev[i] : o->evDepc[i]; }
 #define STAGE_EV(i, stream) do { if (o->stageTiming && o->capSlot < 0) HIPCHK(hipEventRecord(o->ev[i], stream)); } while (0)
 
+// ---- helper thread of the results-to-host copies (see struct orbx)
+static void dl_worker(orbx* o) {
+    (void)hipSetDevice(o->device);
+    for (;;) {
+        orbx::DlReq r;
+        {
+            std::unique_lock<std::mutex> lk(o->dlMu);
+            o->dlCv.wait(lk, [&] { return o->dlStop || !o->dlQueue.empty(); });
+            if (o->dlQueue.empty()) return;                      // dlStop and nothing left to do
+            r = o->dlQueue.front();
+        }
+        hipError_t e = hipEventSynchronize(o->evBatchDone[r.block]);      // host-side wait: the copy below has no device-side dependency
+        if (e == hipSuccess) {
+            if (o->dlKernel) {
+                const size_t n16 = o->blockBytes / 16;               // blockBytes is a multiple of 256
+                const unsigned grid = (unsigned)std::min<size_t>(o->dlGrid, (n16 + 255) / 256);
+                hipLaunchKernelGGL(k_copy_out, dim3(grid), dim3(256), 0, o->stream3, (v4u_t*)r.host, (const v4u_t*)o->rb[r.block].base, n16);
+                e = hipGetLastError();
+            } else
+                e = hipMemcpyAsync(r.host, o->rb[r.block].base, o->blockBytes, hipMemcpyDeviceToHost, o->stream3);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(o->stream3);
+        {
+            std::lock_guard<std::mutex> lk(o->dlMu);
+            if (e != hipSuccess && !o->dlError) o->dlError = (int)e;
+            o->dlQueue.pop_front();
+            o->dlBusy[r.block] = false;
+        }
+        o->dlCv.notify_all();
+    }
+}
+// host-side wait until block b's pending copy (if any) has landed
+static int dl_wait_block(orbx* o, int b) {
+    std::unique_lock<std::mutex> lk(o->dlMu);
+    o->dlCv.wait(lk, [&] { return !o->dlBusy[b]; });
+    if (o->dlError) { set_err("results-to-host copy failed: %s", hipGetErrorString((hipError_t)o->dlError)); o->dlError = 0; return ORBX_E_HIP; }
+    return ORBX_OK;
+}
+static int dl_drain(orbx* o) {
+    std::unique_lock<std::mutex> lk(o->dlMu);
+    o->dlCv.wait(lk, [&] { return o->dlQueue.empty(); });
+    if (o->dlError) { set_err("results-to-host copy failed: %s", hipGetErrorString((hipError_t)o->dlError)); o->dlError = 0; return ORBX_E_HIP; }
+    return ORBX_OK;
+}
+static void dl_stop(orbx* o) {
+    { std::lock_guard<std::mutex> lk(o->dlMu); o->dlStop = true; }
+    o->dlCv.notify_all();
+    if (o->dlThread.joinable()) o->dlThread.join();
+}
+
 extern "C" {
 
 const char* orbx_last_error(void) { return g_err.c_str(); }
@@ -520,7 +588,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     if (const char* e = getenv("ORBX_FAST_QCAP")) o->f3QcapForce = atoi(e);
     if (const char* e = getenv("ORBX_QT_WIDE")) o->qtWideForce = atoi(e) != 0 ? 1 : 0;
     o->blurEarly = !o->blurV2 && getenv("ORBX_BLUR_LATE") == nullptr;
-    o->dlMemcpy = getenv("ORBX_DL_MEMCPY") != nullptr;
+    o->dlKernel = getenv("ORBX_DL_KERNEL") != nullptr;          // A/B: results-to-host copy by k_copy_out instead of the copy engine
     if (const char* e = getenv("ORBX_DL_GRID")) o->dlGrid = std::max(1, atoi(e));
     o->serial = getenv("ORBX_SERIAL") != nullptr;            // A/B switch: simple per-cell reference kernel
     o->scaleFactor = scale_factor;                              // double member initialised from float (ORBextractor.h:96)
@@ -547,8 +615,8 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
         for (auto& e : o->evLvl) if (rc == ORBX_OK && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
         if (rc == ORBX_OK && hipEventCreateWithFlags(&o->evDone, hipEventDisableTiming) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
         if (rc == ORBX_OK && hipEventCreateWithFlags(&o->evGuard, hipEventDisableTiming) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
-        if (rc == ORBX_OK && (hipStreamCreateWithFlags(&o->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&o->evDlStart, hipEventDisableTiming) != hipSuccess ||
-                              hipEventCreateWithFlags(&o->evDl[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&o->evDl[1], hipEventDisableTiming) != hipSuccess)) { rc = ORBX_E_HIP; set_err("copy stream creation failed"); }
+        if (rc == ORBX_OK && hipStreamCreateWithFlags(&o->stream3, hipStreamNonBlocking) != hipSuccess) { rc = ORBX_E_HIP; set_err("copy stream creation failed"); }
+        for (auto& e : o->evBatchDone) if (rc == ORBX_OK && hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
         for (auto& e : o->evDepc) if (rc == ORBX_OK && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
         if (rc == ORBX_OK && (hipMalloc((void**)&o->dStamps, sizeof(unsigned long long) * orbx::kSlots * 4) != hipSuccess ||
                               hipDeviceGetAttribute(&o->wallClockKHz, hipDeviceAttributeWallClockRate, device_id) != hipSuccess || o->wallClockKHz <= 0)) { rc = ORBX_E_HIP; set_err("time stamp setup failed"); }
@@ -586,6 +654,7 @@ void orbx_destroy(orbx_t* o) {
     (void)hipSetDevice(o->device);
     if (o->stream) (void)hipStreamSynchronize(o->stream);
     if (o->stream2) (void)hipStreamSynchronize(o->stream2);
+    dl_stop(o);                                                  // pending copies finish first (their batches are done by now)
     if (o->stream3) (void)hipStreamSynchronize(o->stream3);
     for (auto& G : o->gs) {
         if (G.exec) (void)hipGraphExecDestroy(G.exec);
@@ -593,11 +662,10 @@ void orbx_destroy(orbx_t* o) {
     }
     for (auto& e : o->evDepc) if (e) (void)hipEventDestroy(e);
     for (auto& e : o->evMark) if (e) (void)hipEventDestroy(e);
-    if (o->evDlStart) (void)hipEventDestroy(o->evDlStart);
-    for (auto& e : o->evDl) if (e) (void)hipEventDestroy(e);
+    for (auto& e : o->evBatchDone) if (e) (void)hipEventDestroy(e);
     if (o->stream3) (void)hipStreamDestroy(o->stream3);
     void* ptrs[] = {o->dPyr, o->dBlur, o->dL0, (void*)o->dL0Ptr, o->dCells, o->dTiles, o->dTiles3, o->dB3Th, o->dB3Tv, o->dStrips, o->dX4, o->dRzTasks, o->dXt, o->dYt, o->dCandCnt, o->dCandEnt,
-                    o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->rb[0].base, o->rb[1].base, o->dWork, o->dLap, o->dErr, o->dPattern, o->dOvf, o->dOvfList, o->dOdW, (void*)o->dStamps};
+                    o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->rb[0].base, o->rb[1].base, o->rb[2].base, o->rb[3].base, o->dWork, o->dLap, o->dErr, o->dPattern, o->dOvf, o->dOvfList, o->dOdW, (void*)o->dStamps};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& set : o->evr) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     if (o->evDone) (void)hipEventDestroy(o->evDone);
@@ -613,8 +681,16 @@ void orbx_destroy(orbx_t* o) {
 
 int orbx_max_keypoints(const orbx_t* o) { return o ? o->g.kpCap : ORBX_E_INVALID; }
 
+static int extract_batch_async_impl(orbx_t* o, const uint8_t* const* imgs, int img_space, int nimg, int w, int h, int stride,
+                                    const int* lap01);
 int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_space, int nimg, int w, int h, int stride,
                              const int* lap01) {
+    const int rc = extract_batch_async_impl(o, imgs, img_space, nimg, w, h, stride, lap01);
+    if (rc && o && o->capSlot >= 0) o->capFailed = true;         // orbx_capture_end then discards the half-recorded graph
+    return rc;
+}
+static int extract_batch_async_impl(orbx_t* o, const uint8_t* const* imgs, int img_space, int nimg, int w, int h, int stride,
+                                    const int* lap01) {
     if (!o || !imgs || nimg < 1) return ORBX_E_INVALID;
     if (nimg > o->maxBatch) { set_err("batch %d exceeds max_batch %d", nimg, o->maxBatch); return ORBX_E_CAPACITY; }
     if (w <= 0 || h <= 0) return ORBX_E_EMPTY;
@@ -626,6 +702,7 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
     const Geom& g = o->g;
     hipStream_t st = o->stream;
     const bool capturing = o->capSlot >= 0;
+    if (!capturing) { rc = dl_wait_block(o, o->curBlock); if (rc) return rc; }   // this block may still be on its way to the host
     int l0pitch;
     bool aligned = (stride % 16) == 0;
     for (int i = 0; i < nimg && aligned; ++i) aligned = ((uintptr_t)imgs[i] % 16) == 0;
@@ -765,10 +842,7 @@ int orbx_extract_batch_async(orbx_t* o, const uint8_t* const* imgs, int img_spac
         HIPCHK(hipStreamWaitEvent(st, o->evGuard, 0));
         o->guardPending = false;
     }
-    if (!capturing && o->dlPending[o->curBlock]) {               // ... and this block's previous contents may still be on their way to the host
-        HIPCHK(hipStreamWaitEvent(st, o->evDl[o->curBlock], 0));    // (a graph replay takes this wait in orbx_graph_launch)
-        o->dlPending[o->curBlock] = false;
-    }
+
     hipLaunchKernelGGL(k_slots, dim3(nimg), dim3(256), 0, st, g, o->dSel, o->dSelCnt, o->dLap, o->dKps, o->dWork, o->dN, o->dMono);
     STAGE_EV(4, st);
     HIPCHK(hipStreamWaitEvent(st, dep_ev(o, 9), 0));
@@ -798,13 +872,14 @@ int orbx_capture_begin(orbx_t* o, int slot) {
     if (o->capSlot >= 0) { set_err("a capture is already open"); return ORBX_E_INVALID; }
     if (!o->curW) { set_err("run one batch eagerly first: capture needs the geometry and the per-frame tables in place"); return ORBX_E_INVALID; }
     HIPCHK(hipSetDevice(o->device));
-    HIPCHK(hipStreamSynchronize(o->stream)); HIPCHK(hipStreamSynchronize(o->stream2)); HIPCHK(hipStreamSynchronize(o->stream3));
+    HIPCHK(hipStreamSynchronize(o->stream)); HIPCHK(hipStreamSynchronize(o->stream2));
+    { const int rc = dl_drain(o); if (rc) return rc; }
     orbx::GraphSlot& G = o->gs[slot];
     if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
     if (G.graph) { (void)hipGraphDestroy(G.graph); G.graph = nullptr; }
     G.launches = 0; G.nimg = 0;
     HIPCHK(hipStreamBeginCapture(o->stream, hipStreamCaptureModeThreadLocal));
-    o->capSlot = slot;
+    o->capSlot = slot; o->capFailed = false;
     return ORBX_OK;
 }
 
@@ -823,6 +898,12 @@ int orbx_capture_end(orbx_t* o) {
         set_err("stream capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
         return ORBX_E_HIP;
     }
+    if (o->capFailed || G.nimg < 1) {
+        (void)hipGraphDestroy(graph);
+        G.nimg = 0;
+        set_err(o->capFailed ? "an enqueue failed inside the capture: nothing recorded" : "the capture holds no extraction");
+        return ORBX_E_INVALID;
+    }
     G.graph = graph;
     HIPCHK(hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0));
     return ORBX_OK;
@@ -831,10 +912,7 @@ int orbx_capture_end(orbx_t* o) {
 int orbx_graph_launch(orbx_t* o, int slot) {
     if (!o || slot < 0 || slot >= orbx::kSlots || !o->gs[slot].exec || o->capSlot >= 0) return ORBX_E_INVALID;
     orbx::GraphSlot& G = o->gs[slot];
-    if (G.nimg > 0 && o->dlPending[G.block]) {                   // the block this graph rewrites may still be on its way to the host
-        HIPCHK(hipStreamWaitEvent(o->stream, o->evDl[G.block], 0));
-        o->dlPending[G.block] = false;
-    }
+    if (G.nimg > 0) { const int rc = dl_wait_block(o, G.block); if (rc) return rc; }   // the block this graph rewrites may still be on its way to the host
     HIPCHK(hipGraphLaunch(G.exec, o->stream));
     ++G.launches;
     if (G.nimg > 0) { const int rc = orbx_set_result_block(o, G.block); if (rc) return rc; }
@@ -850,17 +928,17 @@ int orbx_result_download_async(orbx_t* o, void* host_block) {
     if (!o || !host_block || !o->curW) return ORBX_E_INVALID;
     if (o->capSlot >= 0) { set_err("the copy to the host is enqueued eagerly, behind the graph launch, not captured"); return ORBX_E_INVALID; }
     HIPCHK(hipSetDevice(o->device));
-    HIPCHK(hipEventRecord(o->evDlStart, o->stream));
-    HIPCHK(hipStreamWaitEvent(o->stream3, o->evDlStart, 0));
-    if (o->dlMemcpy)
-        HIPCHK(hipMemcpyAsync(host_block, o->rb[o->curBlock].base, o->blockBytes, hipMemcpyDeviceToHost, o->stream3));
-    else {
-        const size_t n16 = o->blockBytes / 16;                   // blockBytes is a multiple of 256
-        const unsigned grid = (unsigned)std::min<size_t>(o->dlGrid, (n16 + 255) / 256);
-        hipLaunchKernelGGL(k_copy_out, dim3(grid), dim3(256), 0, o->stream3, (v4u_t*)host_block, (const v4u_t*)o->rb[o->curBlock].base, n16);
+    const int b = o->curBlock;
+    int rc = dl_wait_block(o, b);                                // an earlier copy of this very block
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(o->evBatchDone[b], o->stream));        // "the batch that fills the block is done"
+    {
+        std::lock_guard<std::mutex> lk(o->dlMu);
+        if (!o->dlThread.joinable()) o->dlThread = std::thread(dl_worker, o);
+        o->dlBusy[b] = true;
+        o->dlQueue.push_back(orbx::DlReq{b, host_block});
     }
-    HIPCHK(hipEventRecord(o->evDl[o->curBlock], o->stream3));
-    o->dlPending[o->curBlock] = true;
+    o->dlCv.notify_all();
     return ORBX_OK;
 }
 
@@ -875,7 +953,7 @@ int orbx_result_block_layout(const orbx_t* o, size_t* off_kps, size_t* off_desc,
 }
 
 int orbx_set_result_block(orbx_t* o, int block) {
-    if (!o || block < 0 || block > 1) return ORBX_E_INVALID;
+    if (!o || block < 0 || block >= orbx::kBlocks) return ORBX_E_INVALID;
     if (block != o->curBlock) o->countsValid = false;
     o->curBlock = block;
     o->dKps = o->rb[block].kps; o->dDesc = o->rb[block].desc; o->dN = o->rb[block].n; o->dMono = o->rb[block].mono;
@@ -884,9 +962,7 @@ int orbx_set_result_block(orbx_t* o, int block) {
 
 int orbx_download_sync(orbx_t* o) {
     if (!o) return ORBX_E_INVALID;
-    HIPCHK(hipSetDevice(o->device));
-    HIPCHK(hipStreamSynchronize(o->stream3));
-    return ORBX_OK;
+    return dl_drain(o);
 }
 
 // caller-placed time stamps on the extractor's stream (which = 0 / 1), e.g. around a run of graph replays: the GPU-side wall
@@ -918,7 +994,7 @@ int orbx_sync(orbx_t* o) {
     HIPCHK(hipSetDevice(o->device));
     HIPCHK(hipStreamSynchronize(o->stream));
     HIPCHK(hipStreamSynchronize(o->stream2));
-    HIPCHK(hipStreamSynchronize(o->stream3));
+    { const int rc = dl_drain(o); if (rc) return rc; }
     int e = 0;
     HIPCHK(hipMemcpy(&e, o->dErr, sizeof(int), hipMemcpyDeviceToHost));
     if (e) { set_err("device-side overflow flag %d", e); (void)hipMemset(o->dErr, 0, sizeof(int)); return ORBX_E_INTERNAL; }

@@ -310,7 +310,10 @@ def test_graph_replay_and_result_blocks_bit_exact(pkg, oracle, synth):
         assert L.orbm_knn2_batch_async(mt.h, r["desc"] + cap * 32, cap, r["counts"] + 4, r["desc"], cap, r["counts"], n - 1, cap,
                                        idx2.ptr + cap * 8, dist2.ptr + cap * 8) == 0
 
-    assert L.orbx_capture_begin(ex.h, 0) < 0                     # nothing has run eagerly yet -> refused... geometry exists, tables do not
+    assert L.orbx_capture_begin(ex.h, 0) == 0                    # nothing has run eagerly yet: the per-frame tables are not in place,
+    with pytest.raises(pkg.OrbError):                            # so the enqueue is refused and the capture comes back empty-handed
+        ex.enqueue_device(arr, w, h, stride)
+    assert L.orbx_capture_end(ex.h) < 0 and L.orbx_graph_launch(ex.h, 0) < 0
     enqueue(0); enqueue(1)
     ex.sync()
     for slot in range(4):

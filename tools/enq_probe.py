@@ -14,7 +14,7 @@ for cfg, extra in (("c2", []), ("c4", []), ("c4", ["--batch", "512"]), ("c2", ["
     tg = td = 0.0
     t0 = time.perf_counter()
     for _ in range(20):
-        blk = wl.k & 1
+        blk = wl.k % wl.nblk
         a = time.perf_counter()
         if wl.graph:
             L.orbx_graph_launch(wl.ex.h, wl.k % wl.nslots)
