@@ -21,6 +21,11 @@ extern "C" {
 enum { ORBM_OK = 0, ORBM_E_INVALID = -2, ORBM_E_CAPACITY = -3, ORBM_E_HIP = -5 };
 enum { ORBM_HOST = 0, ORBM_DEVICE = 1 };
 enum { ORBM_TH_HIGH = 100, ORBM_TH_LOW = 50, ORBM_HISTO_LENGTH = 30 };   /* ORBmatcher.cc:36-38 */
+/* match[] values of the searches that write into an EXISTING Frame::mvpMapPoints (M4, M5 and the fisheye twin of M4):
+ * >= 0 the query matched here; ORBM_NO_MATCH the slot was not touched; ORBM_MATCH_PRUNED the slot was assigned and then culled
+ * by the rotation-consistency check -- the reference leaves NULL there (ORBmatcher.cc:2700-2708, 2843-2847), whatever the slot
+ * held before, so a wrapper must clear it. */
+enum { ORBM_NO_MATCH = -1, ORBM_MATCH_PRUNED = -2 };
 
 typedef struct orbm orbm_t;       /* owns a stream + scratch on one device */
 int orbm_create(orbm_t** out, int device_id);

@@ -133,7 +133,7 @@ int orbref_search_by_projection_frame(const orbref_frame_t* cur, const uint8_t* 
         rh.maxima(ind);
         for (int b = 0; b < HISTO_LENGTH; ++b)
             if (b != ind[0] && b != ind[1] && b != ind[2])
-                for (int idx : rh.bins[b]) { match[idx] = -1; nmatches--; }
+                for (int idx : rh.bins[b]) { match[idx] = -2; nmatches--; }   // assigned, then culled: the reference NULLs the slot (:2700-2708, :2843-2847)
     }
     return nmatches;
 }
@@ -428,7 +428,7 @@ int orbref_search_by_projection_kf(const orbref_frame_t* cur, const uint8_t* blo
         rh.maxima(ind);
         for (int b = 0; b < HISTO_LENGTH; ++b)
             if (b != ind[0] && b != ind[1] && b != ind[2])
-                for (int idx : rh.bins[b]) { match[idx] = -1; nmatches--; }
+                for (int idx : rh.bins[b]) { match[idx] = -2; nmatches--; }   // assigned, then culled: the reference NULLs the slot (:2700-2708, :2843-2847)
     }
     return nmatches;
 }
@@ -700,7 +700,7 @@ int orbref_search_by_projection_frame_fisheye(const orbref_frame_t* cur_l, const
         rh.maxima(ind);
         for (int b = 0; b < HISTO_LENGTH; ++b)
             if (b != ind[0] && b != ind[1] && b != ind[2])
-                for (int idx : rh.bins[b]) { if (idx < Nleft) match_l[idx] = -1; else match_r[idx - Nleft] = -1; nmatches--; }
+                for (int idx : rh.bins[b]) { if (idx < Nleft) match_l[idx] = -2; else match_r[idx - Nleft] = -2; nmatches--; }
     }
     return nmatches;
 }

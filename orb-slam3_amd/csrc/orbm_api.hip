@@ -250,10 +250,11 @@ struct RotHist {                                             // rotation-consist
 // runs k_window for nq windows against frame f; candidate lists come back in host vectors
 int window_pass(orbm* m, const orbm_frame_t* f, int nq, const float* qx, const float* qy, const float* qr,
                 const int32_t* minl, const int32_t* maxl, const float* qur, const float* qer, const uint8_t* qdesc,
-                int& cap, std::vector<int>& cnt, std::vector<int>& idx, std::vector<int>& dist) {
+                int& cap, std::vector<int>& cnt, std::vector<int>& idx, std::vector<int>& dist, bool retry = false) {
     // `cap` in: capacity of a window on the device; out: row stride of idx / dist (= the longest candidate list, >= 1)
     cnt.assign(nq, 0);
     if (nq == 0 || f->n == 0) return ORBM_OK;
+    if (const char* e = retry ? nullptr : getenv("ORBM_WINDOW_CAP")) cap = std::max(1, std::min(cap, atoi(e)));   // test knob: a small first capacity forces the retry below
     MHIPCHK(hipSetDevice(m->device));
     DevBuf dk, dd, du, dgs, dgi, dqx, dqy, dqr, dmin, dmax, dqu, dqe, dqd, dcnt, didx, ddist, dovf, dpack;
     arena_reset(m);
@@ -299,8 +300,17 @@ int window_pass(orbm* m, const orbm_frame_t* f, int nq, const float* qx, const f
         memcpy(idx.data(), dpack.host(), sizeof(int) * pn);
         memcpy(dist.data(), (const int*)dpack.host() + pn, sizeof(int) * pn);
     }
+    if (ovf) {
+        // Frame::GetFeaturesInArea is unbounded (Frame.cc:784-871): a window that holds more than the default capacity (dense
+        // frames, the 100-px initialisation window) is simply run again with room for every keypoint of the frame
+        if (devCap < f->n) {
+            cap = f->n;
+            return window_pass(m, f, nq, qx, qy, qr, minl, maxl, qur, qer, qdesc, cap, cnt, idx, dist, true);
+        }
+        set_merr("a search window returned more than %d candidates", devCap);
+        return ORBM_E_CAPACITY;
+    }
     cap = std::max(maxc, 1);
-    if (ovf) { set_merr("a search window returned more than %d candidates", devCap); return ORBM_E_CAPACITY; }
     return ORBM_OK;
 }
 
@@ -429,7 +439,7 @@ int orbm_search_by_projection_frame(orbm_t* m, const orbm_frame_t* cur, const ui
         rh.maxima(ind);
         for (int b = 0; b < ORBM_HISTO_LENGTH; ++b)
             if (b != ind[0] && b != ind[1] && b != ind[2])
-                for (int k : rh.bins[b]) { match[k] = -1; nmatches--; }
+                for (int k : rh.bins[b]) { match[k] = ORBM_MATCH_PRUNED; nmatches--; }
     }
     return nmatches;
 }
@@ -681,7 +691,7 @@ int orbm_search_by_projection_kf(orbm_t* m, const orbm_frame_t* cur, const uint8
         rh.maxima(ind);
         for (int b = 0; b < ORBM_HISTO_LENGTH; ++b)
             if (b != ind[0] && b != ind[1] && b != ind[2])
-                for (int k : rh.bins[b]) { match[k] = -1; nmatches--; }
+                for (int k : rh.bins[b]) { match[k] = ORBM_MATCH_PRUNED; nmatches--; }
     }
     return nmatches;
 }
@@ -1041,7 +1051,7 @@ int orbm_search_by_projection_frame_fisheye(orbm_t* m, const orbm_frame_t* cur_l
         rh.maxima(ind);
         for (int b = 0; b < ORBM_HISTO_LENGTH; ++b)
             if (b != ind[0] && b != ind[1] && b != ind[2])
-                for (int k : rh.bins[b]) { if (k < Nleft) match_l[k] = -1; else match_r[k - Nleft] = -1; nmatches--; }
+                for (int k : rh.bins[b]) { if (k < Nleft) match_l[k] = ORBM_MATCH_PRUNED; else match_r[k - Nleft] = ORBM_MATCH_PRUNED; nmatches--; }
     }
     return nmatches;
 }

@@ -44,7 +44,7 @@ public:
         const int n = orbx_extract(h, image.data, image.cols, image.rows, (int)image.step, vLappingArea[0], vLappingArea[1],
                                    kpbuf.data(), descbuf.data(), cap, &mono);
         if (n < 0) throw std::runtime_error(std::string("orbx_extract: ") + orbx_last_error());
-        if (n == 0) _descriptors.release(); else _descriptors.create(n, 32, cv::CV_8U);
+        if (n == 0) _descriptors.release(); else _descriptors.create(n, 32, CV_8U);
         _keypoints.resize(n);
         static_assert(sizeof(cv::KeyPoint) == sizeof(orbx_kp_t), "KeyPoint layout");
         if (n) {
@@ -53,6 +53,7 @@ public:
             for (int i = 0; i < n; ++i) std::memcpy(d.ptr(i), descbuf.data() + (size_t)i * 32, 32);
         }
         pyramidStale = true;
+        if (hostPyramid) FetchImagePyramid();
         return mono;
     }
 
@@ -63,15 +64,18 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return table(2); }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return table(3); }
 
-    // include/ORBextractor.h:83 -- Frame::ComputeStereoMatches slices these (Frame.cc:1168,1194).  The levels live in
-    // HBM; call FetchImagePyramid() before reading them on the host (orbm_stereo_matches needs no host copy at all).
+    // include/ORBextractor.h:83 -- Frame::ComputeStereoMatches slices these on the host (Frame.cc:1168,1194), so by default
+    // every operator() copies the levels back (about 1.4x the image, one copy per level).  An integration whose stereo
+    // association runs on the device (orbm_stereo_matches reads the levels in HBM) switches that off with
+    // KeepPyramidOnDevice(true) and calls FetchImagePyramid() only if it ever needs the pixels.
     std::vector<cv::Mat> mvImagePyramid;
+    void KeepPyramidOnDevice(bool on) { hostPyramid = !on; }
     void FetchImagePyramid() {
         if (!h || !pyramidStale) return;
         for (int l = 0; l < nlevels; ++l) {
             int w = 0, hh = 0;
             orbx_level_size(h, l, &w, &hh);
-            mvImagePyramid[l].create(hh, w, cv::CV_8U);
+            mvImagePyramid[l].create(hh, w, CV_8U);
             if (orbx_level_image(h, 0, l, 0, mvImagePyramid[l].data, (int)mvImagePyramid[l].step) < 0)
                 throw std::runtime_error(std::string("orbx_level_image: ") + orbx_last_error());
         }
@@ -102,7 +106,7 @@ protected:
     int nlevels, iniThFAST, minThFAST;
     int device = 0, maxW = 0, maxH = 0;
     orbx_t* h = nullptr;
-    bool pyramidStale = false;
+    bool pyramidStale = false, hostPyramid = true;
     std::vector<orbx_kp_t> kpbuf;
     std::vector<uint8_t> descbuf;
 };
