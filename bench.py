@@ -42,7 +42,7 @@ CONFIGS = {
     "c2": (752, 480, 1000, 512, (0, 1000), "configs[1]"),
     "c5": (1920, 1080, 4000, 64, (0, 1000), "configs[4]"),
     "c4": (512, 512, 1500, 16, (0, 511), "configs[3]"),
-    "c3": (752, 480, 1200, 128, (0, 0), "configs[2]"),
+    "c3": (752, 480, 1200, 256, (0, 0), "configs[2]"),
 }
 
 
@@ -189,7 +189,10 @@ class OrbWorkload:
             self.inv_w = float(np.float32(64) / np.float32(W)); self.inv_h = float(np.float32(48) / np.float32(H))   # Frame.cc:401-402
         # ---- where the results land on the host: pinned, one block per array (reused every step, like a Frame's mvKeys)
         self.layout = ex.result_block_layout()                  # one block = [kps | desc | counts | monos], moved by ONE copy
-        self.h_blk = [pkg.PinnedBuffer(self.layout[4]) for _ in range(self.nblk)]
+        self.host_bytes = self.layout[4]
+        if self.cfg == "c3":
+            self._setup_c3()                                    # attaches the matcher's per-block outputs behind the block
+        self.h_blk = [pkg.PinnedBuffer(self.host_bytes) for _ in range(self.nblk)]
         self.download = True
         self.graph = args.launch == "graph" and args.match == "knn2"
         self.nslots = 4
@@ -224,10 +227,68 @@ class OrbWorkload:
                                          P, cap, self.idx2.ptr, self.dist2.ptr)
             assert rc == 0, rc
         else:
-            self._enqueue_c3()
+            self._enqueue_c3(blk)
 
-    def _enqueue_c3(self):
-        raise SystemExit("config c3 needs the batched stereo path (not in this build)")
+    # ---- config C3 (EuRoC stereo): ComputeStereoMatches per pair, ComputeBoW buckets of the left images, and one
+    # SearchForTriangulation_ of every left image against the left image of the previous step (the KeyFrame before it)
+    MBF = 47.90639384423901
+    MB = MBF / 435.2046959714599                                # Examples/Stereo/EuRoC.yaml:9,28
+
+    def _setup_c3(self):
+        import tempfile
+        np, pkg, L, B, cap = self.np, self.pkg, self.L, self.B, self.cap
+        P = B // 2
+        rng = np.random.default_rng(4242)
+        # synthetic k = 10, L = 3 vocabulary in DBoW2's text format (ORBvoc.txt is a missing blob in the reference snapshot)
+        lines = ["10 3 0 0"]
+        frontier, nid = [(0, 0)], 0
+        while frontier:
+            pid, lvl = frontier.pop(0)
+            for _ in range(10):
+                nid += 1
+                leaf = lvl + 1 == 3
+                lines.append("%d %d %s %r" % (pid, 1 if leaf else 0, " ".join(map(str, rng.integers(0, 256, 32))), float(rng.uniform(0.1, 9.0))))
+                if not leaf:
+                    frontier.append((nid, lvl + 1))
+        self.voc_path = os.path.join(tempfile.mkdtemp(prefix="orbvoc"), "voc.txt")
+        open(self.voc_path, "w").write("\n".join(lines) + "\n")
+        self.voc = pkg.ORBVocabulary(self.mt, self.voc_path)
+        self.levelsup = 1                                       # node level 2 of 3: 100 buckets (ORBvoc: level 2 of 6 with levelsup 4)
+        self.F12 = np.array([0, 0, 0, 0, 0, 0.11, 0, -0.11, 0], np.float32)    # a fixed small sideways motion between identical pinhole cameras
+        self.ep = (1.0e4, 240.0)
+        self.sf = self.ex.GetScaleFactors(); self.sig2 = self.ex.GetScaleSigmaSquares()
+        # per result block: mvuRight, mvDepth, SAD scratch, kept counts, bucket ids of the left images, match lists; they travel to the host with the block
+        self.c3 = []
+        self.c3_off = None
+        for blk in range(self.nblk):
+            d = dict(ur=pkg.DeviceBuffer(P * cap * 4), dp=pkg.DeviceBuffer(P * cap * 4), sad=pkg.DeviceBuffer(P * cap * 4), kept=pkg.DeviceBuffer(P * 4),
+                     nodes=pkg.DeviceBuffer(B * cap * 4), m12=pkg.DeviceBuffer(P * cap * 4), nm=pkg.DeviceBuffer(P * 4))
+            offs = {}
+            for key in ("ur", "dp", "kept", "m12", "nm"):
+                o = C.c_size_t()
+                rc = L.orbx_block_attach(self.ex.h, blk, d[key].ptr, d[key].nbytes, C.byref(o))
+                assert rc == 0, rc
+                offs[key] = int(o.value)
+                self.host_bytes = max(self.host_bytes, offs[key] + ((d[key].nbytes + 255) & ~255))
+            self.c3_off = offs
+            self.c3.append(d)
+
+    def _enqueue_c3(self, blk):
+        L, mt, ex, r, cap, P, B = self.L, self.mt, self.ex, self.res[blk], self.cap, self.B // 2, self.B
+        cur, prev = self.c3[blk], self.c3[(blk - 1) % self.nblk]
+        rp = self.res[(blk - 1) % self.nblk]
+        rc = L.orbm_stereo_batch_async(mt.h, ex.h, 0, P, P, r["kps"], r["desc"], r["counts"], cap, self.MB, self.MBF, cur["ur"].ptr, cur["dp"].ptr, cur["sad"].ptr, cur["kept"].ptr)
+        assert rc == 0, (rc, L.orbm_last_error())
+        rc = L.orbm_bow_nodes_batch_async(mt.h, self.voc.h, r["desc"], B * cap, self.levelsup, cur["nodes"].ptr)     # ComputeBoW buckets, left and right images
+        assert rc == 0, (rc, L.orbm_last_error())
+        # KeyFrame 1 of pair p = its left image now; KeyFrame 2 = the RIGHT image of the same pair as the previous step left it in its
+        # result block: another view of the same scene whose epipolar geometry is F12's (sideways baseline), standing in for the
+        # neighbouring KeyFrame LocalMapping matches against.  Right images carry no mvuRight (mono features).
+        rc = L.orbm_triangulation_batch_async(mt.h, P, cap, r["kps"], r["desc"], r["counts"], cur["nodes"].ptr, cur["ur"].ptr,
+                                              rp["kps"] + P * cap * 28, rp["desc"] + P * cap * 32, rp["counts"] + 4 * P, prev["nodes"].ptr + P * cap * 4, None,
+                                              self.F12.ctypes.data_as(C.c_void_p), self.ep[0], self.ep[1], self.sf.ctypes.data_as(C.c_void_p),
+                                              self.sig2.ctypes.data_as(C.c_void_p), 8, 0, 0, cur["m12"].ptr, cur["nm"].ptr)
+        assert rc == 0, (rc, L.orbm_last_error())
 
     def _capture(self):
         L, ex = self.L, self.ex
@@ -382,7 +443,82 @@ def cpu_baseline(wl, args):
         out["cpu_baseline"] = {"value": 2 * P / tcpu, "unit": "frames/s", "cores": 2, "kind": "port",
                                "sample": "%d stereo pairs of the same synthetic stream through oracle/liborbref.so: two extractions on two "
                                          "threads (Frame.cc:1363-1364), then the 2-NN of left x right on one" % P}
+    elif wl.cfg == "c3":
+        # per stereo pair: two extractions on two threads (Frame.cc:132-137), ComputeStereoMatches, ComputeBoW of the left image and
+        # one SearchForTriangulation_ against the previous pair's left image -- the oracle's restatements, same inputs as the GPU step
+        half = wl.B // 2
+        P = max(2, min(half, ns // 8))
+        refs = [orbref.Extractor(nF, 1.2, 8, 20, 7) for _ in range(2)]
+        OM = orbref._oracle_matcher_class()()
+        voc = orbref.Vocabulary(wl.voc_path)
+        nmatch = []
+        tc = time.perf_counter()
+        for p in range(P):
+            res = [None, None]
+
+            def one(side, idx):
+                res[side] = refs[side](imgs[idx], lap)
+            th = [threading.Thread(target=one, args=(0, p % half)), threading.Thread(target=one, args=(1, half + p % half))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            (nl, kl, dl, _), (nr, kr, dr, _) = res
+            kept, ur, dp = OM.ComputeStereoMatches(refs[0], refs[1], kl, dl, kr, dr, wl.MB, wl.MBF)
+            fv = c3_feature_vector(voc.transform(dl, wl.levelsup)[3])
+            fvr = c3_feature_vector(voc.transform(dr, wl.levelsup)[3])
+            n_t, m12 = OM.SearchForTriangulation(kl, dl, np.zeros(nl, np.uint8), ur, fv, kr, dr, np.zeros(nr, np.uint8), None, fvr,
+                                                 wl.F12, wl.ep, wl.sf, wl.sig2, only_stereo=False, coarse=False, check_ori=False)
+            nmatch.append(n_t)
+        tcpu = time.perf_counter() - tc
+        out["cpu_baseline"] = {"value": 2 * P / tcpu, "unit": "frames/s", "cores": 2, "kind": "port",
+                               "sample": "%d stereo pairs of the same synthetic stream through oracle/liborbref.so: two extractions on two threads "
+                                         "(Frame.cc:132-137), then ComputeStereoMatches, ComputeBoW buckets of both images and SearchForTriangulation_ (left image vs the right image as the neighbouring view) on one" % P,
+                               "triangulation_matches_per_pair": float(np.mean(nmatch)) if nmatch else None}
     return out
+
+
+def c3_feature_vector(nodes):
+    """DBoW2 FeatureVector (std::map<node, vector<idx>>) as CSR: nodes ascending, indices in feature order."""
+    import numpy as np
+    order = np.argsort(nodes, kind="stable")
+    un, start = np.unique(nodes[order], return_index=True)
+    return un.astype(np.int32), np.append(start, len(nodes)).astype(np.int32), order.astype(np.int32)
+
+
+def c3_verify(wl, blk):
+    """Outside the timed region: the last step's stereo points and triangulation match lists, as they arrived in the pinned host
+    block, against the oracle on the same images (pair 0 and the last pair)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orbref
+    P, cap, half = wl.B // 2, wl.cap, wl.B // 2
+    hb = wl.h_blk[blk].bytes
+    off = wl.c3_off
+    ur_h = hb[off["ur"]:off["ur"] + 4 * P * cap].view(np.float32).reshape(P, cap)
+    dp_h = hb[off["dp"]:off["dp"] + 4 * P * cap].view(np.float32).reshape(P, cap)
+    kept_h = hb[off["kept"]:off["kept"] + 4 * P].view(np.int32)
+    m12_h = hb[off["m12"]:off["m12"] + 4 * P * cap].view(np.int32).reshape(P, cap)
+    nm_h = hb[off["nm"]:off["nm"] + 4 * P].view(np.int32)
+    OM = orbref._oracle_matcher_class()()
+    voc = orbref.Vocabulary(wl.voc_path)
+    ok = True
+    cache = {}
+
+    def pair(p):
+        if p not in cache:
+            ol, orr = orbref.Extractor(wl.nF, 1.2, 8, 20, 7), orbref.Extractor(wl.nF, 1.2, 8, 20, 7)
+            nl, kl, dl, _ = ol(wl.host_imgs[p], wl.lap); nr, kr, dr, _ = orr(wl.host_imgs[half + p], wl.lap)
+            kept, ur, dp = OM.ComputeStereoMatches(ol, orr, kl, dl, kr, dr, wl.MB, wl.MBF)
+            cache[p] = (nl, kl, dl, kept, ur, dp, c3_feature_vector(voc.transform(dl, wl.levelsup)[3]), nr, kr, dr, c3_feature_vector(voc.transform(dr, wl.levelsup)[3]))
+        return cache[p]
+    for p in sorted({0, P - 1}):
+        nl, kl, dl, kept, ur, dp, fv, nr, kr, dr, fvr = pair(p)
+        ok = ok and kept == int(kept_h[p]) and ur_h[p, :nl].tobytes() == ur.tobytes() and dp_h[p, :nl].tobytes() == dp.tobytes()
+        n_t, m12 = OM.SearchForTriangulation(kl, dl, np.zeros(nl, np.uint8), ur, fv, kr, dr, np.zeros(nr, np.uint8), None, fvr,
+                                             wl.F12, wl.ep, wl.sf, wl.sig2, only_stereo=False, coarse=False, check_ori=False)
+        ok = ok and n_t == int(nm_h[p]) and np.array_equal(m12_h[p, :nl], m12)
+    return bool(ok), int(kept_h.sum()), int(nm_h.sum())
 
 
 def main():
@@ -533,10 +669,11 @@ def report(wl, args, world, dt, dt_res, t_enq, gpu_wall, extra, total_kp, frames
     legs = {"c2": "dense 2-NN Hamming match (int8 MFMA) of every frame against the previous one",
             "c5": "dense 2-NN Hamming match (int8 MFMA) of every frame against the previous one",
             "c4": "%d fisheye stereo pairs: brute-force 2-NN of left x right descriptors per pair (ComputeStereoFishEyeMatches)" % (B // 2),
-            "c3": "%d stereo pairs: ComputeStereoMatches per pair + SearchForTriangulation against the previous pair" % (B // 2)}
+            "c3": "%d stereo pairs: ComputeStereoMatches per pair, ComputeBoW buckets (synthetic k=10 L=3 vocabulary) and one SearchForTriangulation_ per pair "
+                  "(its left image against the right image of the previous step as the neighbouring KeyFrame)" % (B // 2)}
     if args.match == "window":
         legs["c2"] = legs["c5"] = "Frame grid build and SearchByProjection window match (th=15) of every keypoint in the previous frame"
-    d2h = wl.layout[4]
+    d2h = wl.host_bytes
     out = {
         "metric": "ORB extract+match frames/sec @%dx%d, %d feat" % (W, H, nF),
         "config": {"workload": (cname + ": " if named else "other size (not a named config): ") +
@@ -582,6 +719,11 @@ def report(wl, args, world, dt, dt_res, t_enq, gpu_wall, extra, total_kp, frames
         n = len(kps)
         ok = ok and n == int(n_pin[i]) and mono == int(m_pin[i]) and np.array_equal(kps.view(np.uint8).reshape(n, 28), k_pin[i, :n]) and np.array_equal(desc, d_pin[i, :n])
     out["host_copy_matches_device"] = ok
+    if wl.cfg == "c3":
+        ok3, nst, ntri = c3_verify(wl, blk)
+        out["stereo_and_triangulation_match_oracle"] = ok3
+        out["config"]["stereo_points_last_step"] = nst
+        out["config"]["triangulation_matches_last_step"] = ntri
     if world == 1 and args.cpu_sample > 0:
         out.update(cpu_baseline(wl, args))
     return out

@@ -230,6 +230,28 @@ int orbm_track_window_batch_async(orbm_t*, const orbm_kp_t* kps, const uint8_t* 
                                   int q_first, int t_first, int npairs, float th, const float* scale_factors_host, int nlevels,
                                   float dx, float dy, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);
 
+/* ---- batched, DEVICE-resident stereo step (config C3: EuRoC stereo).  All pointers are device pointers; enqueue only.
+ * orbm_stereo_batch_async: M15 Frame::ComputeStereoMatches (Frame.cc:1027-1276) for `npairs` stereo pairs of ONE extractor
+ * batch: pair p = frames (first_l + p, first_r + p); kps / desc / counts = that extractor's result block (orbx_result_device),
+ * cap = orbx_max_keypoints.  The row-band candidates, Hamming, SAD slide and parabola run per left keypoint on the
+ * device-resident pyramids; the median cut (:1261-1275) is a second kernel.  Outputs [npairs][cap]: uright (mvuRight), depth
+ * (mvDepth), sad (scratch: best SAD or -1); kept[npairs] = stereo points that survive the cut.
+ * orbm_bow_nodes_batch_async: Frame::ComputeBoW's FeatureVector bucket of every descriptor row (8(f).1 tree descent, node at
+ * `levelsup` levels above the leaves) for nrows rows of a result block: node_id[nrows].
+ * orbm_triangulation_batch_async: M10 SearchForTriangulation_ (ORBmatcher.cc:1388-1629; pinhole, no MapPoints attached, no
+ * orientation check: how LocalMapping calls it, LocalMapping.cc:514-516,592) for `npairs` KeyFrame pairs: KeyFrame 1 of pair p
+ * = row p of the *1 arrays ([npairs][cap] slices of a result block + its node ids and mvuRight), KeyFrame 2 likewise.  A
+ * bucket = equal node id, walked in ascending index order as the FeatureVector is.  matches12 [npairs][cap] = idx2 or -1,
+ * nmatches[npairs]. */
+int orbm_stereo_batch_async(orbm_t*, void* extractor, int first_l, int first_r, int npairs, const orbm_kp_t* kps, const uint8_t* desc,
+                            const int32_t* counts, int cap, float mb, float mbf, float* uright, float* depth, int32_t* sad, int32_t* kept);
+int orbm_bow_nodes_batch_async(orbm_t*, const struct orbm_vocab* vocab, const uint8_t* desc, int nrows, int levelsup, int32_t* node_id);
+int orbm_triangulation_batch_async(orbm_t*, int npairs, int cap,
+                                   const orbm_kp_t* kps1, const uint8_t* desc1, const int32_t* counts1, const int32_t* node1, const float* uright1,
+                                   const orbm_kp_t* kps2, const uint8_t* desc2, const int32_t* counts2, const int32_t* node2, const float* uright2,
+                                   const float* F12, float epx, float epy, const float* scale_factors2, const float* level_sigma2_2, int nlevels,
+                                   int only_stereo, int coarse, int32_t* matches12, int32_t* nmatches);
+
 /* ---- DBoW2 vocabulary transform (Frame::ComputeBoW, Frame.cc:905-918;
  * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1125-1262, FORB::distance FORB.cpp:81-101) ----
  * The tree lives in HBM; orbm_bow_transform descends it for n descriptors (host pointers) and returns per feature the

@@ -135,6 +135,12 @@ int orbx_graph_launch(orbx_t*, int slot);
  * by batch gets the copy of batch i beside the kernels of batch i+1.  Whoever is about to rewrite a block whose copy has not
  * landed -- orbx_extract_batch_async, orbx_graph_launch, another download of the same block -- waits for it on the host first.
  * Never inside a capture.  orbx_download_sync (or orbx_sync) returns when every requested copy has landed. */
+/* caller-owned DEVICE buffers that belong to a block's batch (what a matcher computed from it: mvuRight, mvDepth, match lists)
+ * can ride along: after orbx_block_attach(o, block, dev, bytes, &off) every download of that block also copies `bytes` from
+ * `dev` to host_block + off (off >= the block's own size; attachments follow each other, 256-byte aligned, so the pinned block
+ * must be that much larger).  A change of image size, or orbx_block_detach_all, drops the attachments. */
+int orbx_block_attach(orbx_t*, int block, const void* dev, size_t bytes, size_t* host_offset);
+int orbx_block_detach_all(orbx_t*);
 int orbx_result_block_layout(const orbx_t*, size_t* off_kps, size_t* off_desc, size_t* off_counts, size_t* off_monos, size_t* bytes);
 int orbx_result_download_async(orbx_t*, void* host_block);
 int orbx_set_result_block(orbx_t*, int block);

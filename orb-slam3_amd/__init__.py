@@ -29,11 +29,12 @@ EXPORTS = [
     "orbx_level_image", "orbx_scale_tables", "orbx_features_per_level", "orbx_level_candidates",
     "orbx_level_selected", "orbx_last_timings", "orbx_set_stage_timing", "orbx_mean_timings", "orbx_stream_wait_results", "orbx_stream_wait_other", "orbx_guard_results", "orbx_gray_from_color", "orbx_remap_linear", "orbx_clahe", "orbx_algorithmic_bytes", "orbx_blur_in_pass", "orbx_stream", "orbx_dev_alloc",
     "orbx_dev_free", "orbx_memcpy_h2d", "orbx_memcpy_d2h", "orbx_device_count",
-    "orbx_capture_begin", "orbx_capture_end", "orbx_graph_launch", "orbx_result_download_async", "orbx_result_block_layout", "orbx_download_sync",
+    "orbx_capture_begin", "orbx_capture_end", "orbx_graph_launch", "orbx_result_download_async", "orbx_result_block_layout", "orbx_block_attach", "orbx_block_detach_all", "orbx_download_sync",
     "orbx_host_alloc", "orbx_host_free", "orbx_set_result_block", "orbx_mark", "orbx_mark_elapsed_ms",
     # include/orbm.h
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_sync", "orbm_stream", "orbm_set_stream", "orbm_hamming",
     "orbm_three_maxima", "orbm_knn2_batch", "orbm_knn2_batch_async", "orbm_last_timing",
+    "orbm_stereo_batch_async", "orbm_bow_nodes_batch_async", "orbm_triangulation_batch_async",
 ]
 
 
@@ -97,6 +98,8 @@ def lib():
         L.orbx_result_download_async.argtypes = [vp, vp]
         L.orbx_result_block_layout.argtypes = [vp] + [C.POINTER(C.c_size_t)] * 5
         L.orbx_download_sync.argtypes = [vp]
+        L.orbx_block_attach.argtypes = [vp, ci, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.orbx_block_detach_all.argtypes = [vp]
         L.orbx_set_result_block.argtypes = [vp, ci]
         L.orbx_host_alloc.restype = vp
         L.orbx_host_alloc.argtypes = [C.c_size_t]
@@ -115,6 +118,9 @@ def lib():
         L.orbm_knn2_batch.argtypes = [vp, ci, vp, ci, vp, vp, ci, vp, ci, vp, vp]
         L.orbm_knn2_batch_async.argtypes = [vp, vp, ci, vp, vp, ci, vp, ci, ci, vp, vp]
         L.orbm_last_timing.argtypes = [vp, vp]
+        L.orbm_stereo_batch_async.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp, ci, C.c_float, C.c_float, vp, vp, vp, vp]
+        L.orbm_bow_nodes_batch_async.argtypes = [vp, vp, vp, ci, ci, vp]
+        L.orbm_triangulation_batch_async.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, ci, ci, ci, vp, vp]
         _LIB = L
     return _LIB
 

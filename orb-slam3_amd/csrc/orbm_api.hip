@@ -1321,6 +1321,64 @@ int orbm_stereo_matches(orbm_t* m, void* left, int frame_l, void* right, int fra
     return kept;
 }
 
+// ---- batched, device-resident forms of M15 / 8(f).1 / M10 (config C3 of bench.py: nothing leaves HBM between the extraction and
+// the match lists) ------------------------------------------------------------------------------------------
+extern "C" int orbx_internal_batch_layout(void* o, const uint8_t* const** l0tab, int* l0pitch, const uint8_t** pyr, size_t* frameBytes,
+                                          int* nlevels, int* off, int* pitch, int* w, float* sf, float* isf, int* device, int* maxBatch, int* kpCap);
+
+int orbm_stereo_batch_async(orbm_t* m, void* extractor, int first_l, int first_r, int npairs, const orbm_kp_t* kps, const uint8_t* desc,
+                            const int32_t* counts, int cap, float mb, float mbf, float* uright, float* depth, int32_t* sad, int32_t* kept) {
+    if (!m || !extractor || !kps || !desc || !counts || !uright || !depth || !sad || !kept || npairs < 1 || first_l < 0 || first_r < 0 || cap < 1 || cap > 65535) return ORBM_E_INVALID;
+    StereoBatchLayout B;
+    memset(&B, 0, sizeof B);
+    int nlev = 0, dev = 0, maxBatch = 0, kpCap = 0;
+    if (orbx_internal_batch_layout(extractor, &B.l0, &B.l0pitch, &B.pyr, &B.frameBytes, &nlev, B.off, B.pitch, B.w, B.sf, B.isf, &dev, &maxBatch, &kpCap)) {
+        set_merr("the extractor handle holds no geometry"); return ORBM_E_INVALID;
+    }
+    if (dev != m->device || cap != kpCap || first_l + npairs > maxBatch || first_r + npairs > maxBatch) { set_merr("extractor / matcher mismatch (device, capacity or batch range)"); return ORBM_E_INVALID; }
+    MHIPCHK(hipSetDevice(m->device));
+    int n2 = 64; while (n2 < cap) n2 <<= 1;
+    if (n2 * 4 > 48 * 1024) MHIPCHK(hipFuncSetAttribute((const void*)k_stereo_cut, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 4));
+    m->gridFirst = false;
+    MHIPCHK(rec_time(m, m->e0));
+    hipLaunchKernelGGL(k_stereo_batch, dim3((cap + 3) / 4, npairs), dim3(256), 0, m->stream, (const KpIn*)kps, desc, counts, cap, first_l, first_r, B, mb, mbf,
+                       uright, depth, sad);
+    hipLaunchKernelGGL(k_stereo_cut, dim3(npairs), dim3(256), (size_t)n2 * 4, m->stream, counts, cap, first_l, n2, sad, uright, depth, kept);
+    MHIPCHK(rec_time(m, m->e1));
+    m->timed = true;
+    MHIPCHK(hipGetLastError());
+    return ORBM_OK;
+}
+
+int orbm_bow_nodes_batch_async(orbm_t* m, const orbm_vocab_t* v, const uint8_t* desc, int nrows, int levelsup, int32_t* node_id) {
+    if (!m || !v || !desc || !node_id || nrows < 1) return ORBM_E_INVALID;
+    if (v->device != m->device) { set_merr("vocabulary lives on another device"); return ORBM_E_INVALID; }
+    MHIPCHK(hipSetDevice(m->device));
+    hipLaunchKernelGGL(k_bow_transform, dim3((nrows + 255) / 256), dim3(256), 0, m->stream, desc, nrows, v->dChildStart, v->dChildIdx, v->dDesc, v->dWord, v->dWeight,
+                       v->L, levelsup, (int*)nullptr, node_id, (double*)nullptr);
+    MHIPCHK(hipGetLastError());
+    return ORBM_OK;
+}
+
+int orbm_triangulation_batch_async(orbm_t* m, int npairs, int cap,
+                                   const orbm_kp_t* kps1, const uint8_t* desc1, const int32_t* counts1, const int32_t* node1, const float* uright1,
+                                   const orbm_kp_t* kps2, const uint8_t* desc2, const int32_t* counts2, const int32_t* node2, const float* uright2,
+                                   const float* F12, float epx, float epy, const float* scale_factors2, const float* level_sigma2_2, int nlevels,
+                                   int only_stereo, int coarse, int32_t* matches12, int32_t* nmatches) {
+    if (!m || npairs < 1 || cap < 1 || cap > 65535 || !kps1 || !desc1 || !counts1 || !node1 || !kps2 || !desc2 || !counts2 || !node2 || !F12 || !scale_factors2 ||
+        !level_sigma2_2 || nlevels < 1 || nlevels > 12 || !matches12 || !nmatches) return ORBM_E_INVALID;
+    MHIPCHK(hipSetDevice(m->device));
+    TriParams P;
+    for (int i = 0; i < 9; ++i) P.F12[i] = F12[i];
+    P.epx = epx; P.epy = epy; P.onlyStereo = only_stereo; P.coarse = coarse;
+    for (int i = 0; i < 12; ++i) { P.sf2[i] = scale_factors2[std::min(i, nlevels - 1)]; P.sigma2[i] = level_sigma2_2[std::min(i, nlevels - 1)]; }
+    MHIPCHK(hipMemsetAsync(nmatches, 0, sizeof(int) * npairs, m->stream));
+    hipLaunchKernelGGL(k_triangulate_batch, dim3((cap + 3) / 4, npairs), dim3(256), 0, m->stream, (const KpIn*)kps1, desc1, counts1, node1, uright1,
+                       (const KpIn*)kps2, desc2, counts2, node2, uright2, cap, P, matches12, nmatches);
+    MHIPCHK(hipGetLastError());
+    return ORBM_OK;
+}
+
 // ---- SURVEY 8(f).2 / 8(f).3 ------------------------------------------------------------------------------
 static bool fill_undist(UndistParams& P, const float* k, const float* dist, int ndist, const float* newk) {
     for (double& d : P.k) d = 0.0;

@@ -395,13 +395,13 @@ __global__ __launch_bounds__(256) void k_pairdist(const uint8_t* __restrict__ d1
 // ------------------------------------------------------------------------------------------------
 struct StereoLevels { const uint8_t* L[12]; const uint8_t* R[12]; int pitchL[12], pitchR[12], wR[12]; float sf[12], isf[12]; };
 
-__global__ __launch_bounds__(256) void k_stereo(const KpIn* __restrict__ kl, const uint8_t* __restrict__ dl, int nl,
-                                                const KpIn* __restrict__ kr, const uint8_t* __restrict__ dr, int nr,
-                                                StereoLevels lv, float mb, float mbf, float* __restrict__ uright,
-                                                float* __restrict__ depth, int* __restrict__ bestSad) {
+// LV supplies the pyramids: sf(o), isf(o), L(level), R(level), pitchL(level), pitchR(level), wR(level)
+template <class LV>
+__device__ __forceinline__ void stereo_body(const KpIn* __restrict__ kl, const uint8_t* __restrict__ dl, int nl,
+                                            const KpIn* __restrict__ kr, const uint8_t* __restrict__ dr, int nr,
+                                            const LV& lv, float mb, float mbf, float* __restrict__ uright,
+                                            float* __restrict__ depth, int* __restrict__ bestSad, int iL) {
     const int lane = threadIdx.x & 63;
-    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (iL >= nl) return;
     const KpIn kpL = kl[iL];
     const int levelL = kpL.octave;
     const float vL = kpL.y, uL = kpL.x;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void k_stereo(const KpIn* __restrict__ kl, con
             const int iR = b0 + lane;
             if (iR < nr) {
                 const KpIn kpR = kr[iR];
-                const float r = 2.0f * lv.sf[kpR.octave];
+                const float r = 2.0f * lv.sf(kpR.octave);
                 const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
                 if (rowL >= minr && rowL <= maxr && kpR.octave >= levelL - 1 && kpR.octave <= levelL + 1 &&
                     kpR.x >= minU && kpR.x <= maxU) {
@@ -438,15 +438,15 @@ __global__ __launch_bounds__(256) void k_stereo(const KpIn* __restrict__ kl, con
         if (best != 0xFFFFFFFFu && bestDist < 100 && bestDist < 75) {        // < TH_HIGH to replace the init, < thOrbDist to go on
             const int bestIdxR = (int)(best & 0xFFFFu);
             const float uR0 = kr[bestIdxR].x;
-            const float scaleFactor = lv.isf[levelL];
+            const float scaleFactor = lv.isf(levelL);
             const float scaleduL = roundf(kpL.x * scaleFactor), scaledvL = roundf(kpL.y * scaleFactor);
             const float scaleduR0 = roundf(uR0 * scaleFactor);
             const int w = 5, Lh = 5;
             const float iniu = scaleduR0 + Lh - w, endu = scaleduR0 + Lh + w + 1;
-            if (!(iniu < 0 || endu >= (float)lv.wR[levelL])) {
-                const uint8_t* IL = lv.L[levelL];
-                const uint8_t* IR = lv.R[levelL];
-                const int pl = lv.pitchL[levelL], pr = lv.pitchR[levelL];
+            if (!(iniu < 0 || endu >= (float)lv.wR(levelL))) {
+                const uint8_t* IL = lv.L(levelL);
+                const uint8_t* IR = lv.R(levelL);
+                const int pl = lv.pitchL(levelL), pr = lv.pitchR(levelL);
                 const int cy = (int)scaledvL, cxl = (int)scaleduL, cxr = (int)scaleduR0;
                 int sad[11];
 #pragma unroll
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void k_stereo(const KpIn* __restrict__ kl, con
                     for (int k = 1; k < 10; ++k) if (k - Lh == bestinc) { d1 = (float)sad[k - 1]; d2 = (float)sad[k]; d3 = (float)sad[k + 1]; }
                     const float deltaR = (d1 - d3) / (2.0f * (d1 + d3 - 2.0f * d2));
                     if (!(deltaR < -1 || deltaR > 1)) {
-                        float bestuR = lv.sf[levelL] * ((float)scaleduR0 + (float)bestinc + deltaR);
+                        float bestuR = lv.sf(levelL) * ((float)scaleduR0 + (float)bestinc + deltaR);
                         float disparity = (uL - bestuR);
                         if (disparity >= minD && disparity < maxD) {
                             if (disparity <= 0) { disparity = 0.01; bestuR = (float)((double)uL - 0.01); }
@@ -488,6 +488,173 @@ __global__ __launch_bounds__(256) void k_stereo(const KpIn* __restrict__ kl, con
         }
     }
     if (lane == 0) { uright[iL] = ur_out; depth[iL] = depth_out; bestSad[iL] = sad_out; }
+}
+
+struct StereoLevelsView {                                  // accessor form of StereoLevels (one pair: orbm_stereo_matches)
+    const StereoLevels& s;
+    __device__ float sf(int o) const { return s.sf[o]; }
+    __device__ float isf(int o) const { return s.isf[o]; }
+    __device__ const uint8_t* L(int l) const { return s.L[l]; }
+    __device__ const uint8_t* R(int l) const { return s.R[l]; }
+    __device__ int pitchL(int l) const { return s.pitchL[l]; }
+    __device__ int pitchR(int l) const { return s.pitchR[l]; }
+    __device__ int wR(int l) const { return s.wR[l]; }
+};
+__global__ __launch_bounds__(256) void k_stereo(const KpIn* __restrict__ kl, const uint8_t* __restrict__ dl, int nl,
+                                                const KpIn* __restrict__ kr, const uint8_t* __restrict__ dr, int nr,
+                                                StereoLevels lv, float mb, float mbf, float* __restrict__ uright,
+                                                float* __restrict__ depth, int* __restrict__ bestSad) {
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (iL >= nl) return;
+    const StereoLevelsView v{lv};
+    stereo_body(kl, dl, nl, kr, dr, nr, v, mb, mbf, uright, depth, bestSad, iL);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched, device-resident stereo (config C3): pair p = frames (first_l + p, first_r + p) of ONE extractor batch whose
+// result block (kps / desc / counts, [frames][cap]) and pyramids sit in HBM.  k_stereo_batch = k_stereo per pair;
+// k_stereo_cut = the median cut of Frame.cc:1261-1275 on the device: sort the SAD of the pair's stereo points, take the
+// element at size/2, drop every point with SAD >= 1.5f*1.4f*median.
+// ------------------------------------------------------------------------------------------------
+struct StereoBatchLayout {                                  // where an extractor keeps a batch's pyramids (orbx_internal_batch_layout)
+    const uint8_t* const* l0; int l0pitch; const uint8_t* pyr; size_t frameBytes;
+    int off[12], pitch[12], w[12]; float sf[12], isf[12];
+};
+struct StereoBatchView {
+    const StereoBatchLayout& b; int fl, fr;
+    __device__ float sf(int o) const { return b.sf[o]; }
+    __device__ float isf(int o) const { return b.isf[o]; }
+    __device__ const uint8_t* L(int l) const { return l == 0 ? b.l0[fl] : b.pyr + (size_t)fl * b.frameBytes + b.off[l]; }
+    __device__ const uint8_t* R(int l) const { return l == 0 ? b.l0[fr] : b.pyr + (size_t)fr * b.frameBytes + b.off[l]; }
+    __device__ int pitchL(int l) const { return l == 0 ? b.l0pitch : b.pitch[l]; }
+    __device__ int pitchR(int l) const { return l == 0 ? b.l0pitch : b.pitch[l]; }
+    __device__ int wR(int l) const { return b.w[l]; }
+};
+__global__ __launch_bounds__(256) void k_stereo_batch(const KpIn* __restrict__ kps, const uint8_t* __restrict__ desc, const int* __restrict__ counts,
+                                                      int cap, int first_l, int first_r, StereoBatchLayout B, float mb, float mbf,
+                                                      float* __restrict__ uright, float* __restrict__ depth, int* __restrict__ bestSad) {
+    const int pair = blockIdx.y, fl = first_l + pair, fr = first_r + pair;
+    const int nl = min(counts[fl], cap), nr = min(counts[fr], cap);
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (iL >= nl) return;
+    const StereoBatchView v{B, fl, fr};
+    const size_t o = (size_t)pair * cap;
+    if (nr == 0) { if ((threadIdx.x & 63) == 0) { uright[o + iL] = -1.0f; depth[o + iL] = -1.0f; bestSad[o + iL] = -1; } return; }
+    stereo_body(kps + (size_t)fl * cap, desc + (size_t)fl * cap * 32, nl, kps + (size_t)fr * cap, desc + (size_t)fr * cap * 32, nr, v, mb, mbf,
+                uright + o, depth + o, bestSad + o, iL);
+}
+
+__global__ __launch_bounds__(256) void k_stereo_cut(const int* __restrict__ counts, int cap, int first_l, int n2, const int* __restrict__ bestSad,
+                                                    float* __restrict__ uright, float* __restrict__ depth, int* __restrict__ kept) {
+    extern __shared__ unsigned int cutKeys[];
+    __shared__ int s_m;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int nl = min(counts[first_l + pair], cap);
+    const size_t o = (size_t)pair * cap;
+    if (tid == 0) s_m = 0;
+    __syncthreads();
+    for (int i = tid; i < n2; i += 256) {
+        unsigned int key = 0xFFFFFFFFu;
+        if (i < nl) { const int sdv = bestSad[o + i]; if (sdv >= 0) { key = (unsigned)sdv; atomicAdd(&s_m, 1); } }
+        cutKeys[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned a = cutKeys[i], b = cutKeys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { cutKeys[i] = b; cutKeys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    const int m = s_m;
+    if (m == 0) { if (tid == 0) kept[pair] = 0; return; }
+    const float median = (float)cutKeys[m / 2];
+    const float thDist = 1.5f * 1.4f * median;
+    __syncthreads();
+    if (tid == 0) s_m = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < nl; i += 256) {
+        const int sdv = bestSad[o + i];
+        if (sdv < 0) continue;
+        if ((float)sdv < thDist) ++mine;
+        else { uright[o + i] = -1.0f; depth[o + i] = -1.0f; }
+    }
+    atomicAdd(&s_m, mine);
+    __syncthreads();
+    if (tid == 0) kept[pair] = s_m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_triangulate_batch: ORBmatcher::SearchForTriangulation_ (ORBmatcher.cc:1388-1629, pinhole, orientation check off as
+// LocalMapping calls it) for a batch of KeyFrame pairs held in extractor result blocks.  One wavefront per feature of
+// KeyFrame 1.  Its bucket = the features of KeyFrame 2 with the same vocabulary node (FeatureVector order = ascending
+// index).  The reference walks the bucket keeping `dist <= TH_LOW && dist <= bestDist` candidates that pass the epipole /
+// epipolar gates, so the survivor is the smallest distance among the gate-passing candidates and, on ties, the LAST one:
+// a min-reduction over keys (dist << 16 | 0xFFFF - idx2).  vbMatched2 is not kept by this overload (:1567), so the
+// features of KeyFrame 1 are independent.
+// ------------------------------------------------------------------------------------------------
+struct TriParams { float F12[9]; float epx, epy; float sf2[12], sigma2[12]; int onlyStereo, coarse; };
+__global__ __launch_bounds__(256) void k_triangulate_batch(const KpIn* __restrict__ kps1, const uint8_t* __restrict__ desc1, const int* __restrict__ counts1,
+                                                           const int* __restrict__ node1, const float* __restrict__ ur1,
+                                                           const KpIn* __restrict__ kps2, const uint8_t* __restrict__ desc2, const int* __restrict__ counts2,
+                                                           const int* __restrict__ node2, const float* __restrict__ ur2,
+                                                           int cap, TriParams P, int* __restrict__ matches12, int* __restrict__ nmatches) {
+    const int pair = blockIdx.y, lane = threadIdx.x & 63;
+    const int n1 = min(counts1[pair], cap), n2 = min(counts2[pair], cap);
+    const int i1 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i1 >= n1) return;
+    const size_t o = (size_t)pair * cap;
+    const KpIn kp1 = kps1[o + i1];
+    const int nd = node1[o + i1];
+    const bool bStereo1 = ur1 && ur1[o + i1] >= 0;
+    unsigned int best = 0xFFFFFFFFu;
+    if (!(P.onlyStereo && !bStereo1)) {
+        const uint4* qp = (const uint4*)(desc1 + (o + i1) * 32);
+        const uint4 qlo = qp[0], qhi = qp[1];
+        const u64 a[4] = {(u64)qlo.x | ((u64)qlo.y << 32), (u64)qlo.z | ((u64)qlo.w << 32),
+                          (u64)qhi.x | ((u64)qhi.y << 32), (u64)qhi.z | ((u64)qhi.w << 32)};
+        // the epipolar line of kp1 in image 2 (Pinhole::epipolarConstrain_, Pinhole.cpp:281-287)
+        const float la = kp1.x * P.F12[0] + kp1.y * P.F12[3] + P.F12[6];
+        const float lb = kp1.x * P.F12[1] + kp1.y * P.F12[4] + P.F12[7];
+        const float lc = kp1.x * P.F12[2] + kp1.y * P.F12[5] + P.F12[8];
+        const float den = la * la + lb * lb;
+        for (int b0 = 0; b0 < n2; b0 += 64) {
+            const int i2 = b0 + lane;
+            if (i2 >= n2 || node2[o + i2] != nd) continue;
+            const bool bStereo2 = ur2 && ur2[o + i2] >= 0;
+            if (P.onlyStereo && !bStereo2) continue;
+            const uint4* tp = (const uint4*)(desc2 + (o + i2) * 32);
+            const uint4 lo = tp[0], hi = tp[1];
+            const int d = ham256(a, (u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
+                                 (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32));
+            if (d > 50) continue;                                                // TH_LOW
+            const KpIn kp2 = kps2[o + i2];
+            if (!bStereo1 && !bStereo2) {
+                const float distex = P.epx - kp2.x, distey = P.epy - kp2.y;
+                if (distex * distex + distey * distey < 100 * P.sf2[kp2.octave]) continue;
+            }
+            bool epi = false;
+            if (den != 0) {
+                const float num = la * kp2.x + lb * kp2.y + lc;
+                const float dsqr = num * num / den;
+                epi = (double)dsqr < 3.84 * (double)P.sigma2[kp2.octave];         // float compared with the double product, as written (Pinhole.cpp:295)
+            }
+            if (epi || P.coarse) best = min(best, ((unsigned)d << 16) | (0xFFFFu - (unsigned)i2));
+        }
+    }
+#pragma unroll
+    for (int s_ = 32; s_ > 0; s_ >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, s_));
+    if (lane == 0) {
+        const int res = best == 0xFFFFFFFFu ? -1 : (int)(0xFFFFu - (best & 0xFFFFu));
+        matches12[o + i1] = res;
+        if (res >= 0) atomicAdd(&nmatches[pair], 1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -651,8 +818,8 @@ __global__ __launch_bounds__(256) void k_bow_transform(const uint8_t* __restrict
         final_id = bid;
         if (level == nid_level) nid = final_id;
     }
-    word_id[i] = nword[final_id];
-    weight[i] = nweight[final_id];
+    if (word_id) word_id[i] = nword[final_id];
+    if (weight) weight[i] = nweight[final_id];
     node_id[i] = nid;
 }
 

@@ -94,6 +94,8 @@ struct orbx {
     hipEvent_t evBatchDone[kBlocks] = {};
     std::thread dlThread; std::mutex dlMu; std::condition_variable dlCv;
     struct DlReq { int block; void* host; };
+    struct Attach { const void* dev; size_t bytes, hostOff; };   // caller buffers that travel with a block (orbx_block_attach)
+    std::vector<Attach> attach[kBlocks];
     std::deque<DlReq> dlQueue; bool dlBusy[kBlocks] = {}; bool dlStop = false; int dlError = 0; bool dlKernel = false; int dlGrid = 16;
     // A block is ONE allocation -- [kps | desc | counts | monos] at offKps.. -- so that it reaches the host with a single copy
     // (several back-to-back hipMemcpyAsync on one stream block the calling thread for ~0.4 ms each on this runtime).
@@ -170,6 +172,7 @@ static int build_geometry(orbx* o, int w, int h) {
         G.exec = nullptr; G.graph = nullptr; G.launches = 0; G.nimg = 0;
     }
     o->upPtr.clear(); o->upLap.clear();
+    for (auto& v : o->attach) v.clear();                       // the block layout is about to change
     Geom& g = o->g;
     memset(&g, 0, sizeof g);
     const int L = o->nlevels;
@@ -523,6 +526,8 @@ static void dl_worker(orbx* o) {
                 e = hipGetLastError();
             } else
                 e = hipMemcpyAsync(r.host, o->rb[r.block].base, o->blockBytes, hipMemcpyDeviceToHost, o->stream3);
+            for (const orbx::Attach& a : o->attach[r.block])
+                if (e == hipSuccess) e = hipMemcpyAsync((u8*)r.host + a.hostOff, a.dev, a.bytes, hipMemcpyDeviceToHost, o->stream3);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(o->stream3);
         {
@@ -940,6 +945,25 @@ int orbx_result_download_async(orbx_t* o, void* host_block) {
     }
     o->dlCv.notify_all();
     return ORBX_OK;
+}
+
+// Caller-owned device buffers that belong to a block's batch (a matcher's outputs for that batch: mvuRight, mvDepth, match lists)
+// travel to the host with it: they land behind the block proper, at *host_offset of the pinned host block.
+int orbx_block_attach(orbx_t* o, int block, const void* dev, size_t bytes, size_t* host_offset) {
+    if (!o || block < 0 || block >= orbx::kBlocks || !dev || bytes == 0 || !host_offset || !o->curW) return ORBX_E_INVALID;
+    const int rc = dl_wait_block(o, block);
+    if (rc) return rc;
+    size_t off = o->blockBytes;
+    for (const orbx::Attach& a : o->attach[block]) off = a.hostOff + ((a.bytes + 255) & ~(size_t)255);
+    o->attach[block].push_back(orbx::Attach{dev, bytes, off});
+    *host_offset = off;
+    return ORBX_OK;
+}
+int orbx_block_detach_all(orbx_t* o) {
+    if (!o) return ORBX_E_INVALID;
+    const int rc = dl_drain(o);
+    for (auto& v : o->attach) v.clear();
+    return rc;
 }
 
 int orbx_result_block_layout(const orbx_t* o, size_t* off_kps, size_t* off_desc, size_t* off_counts, size_t* off_monos, size_t* bytes) {
@@ -1372,6 +1396,17 @@ int orbx_internal_levels(orbx_t* o, int frame, int* nlevels, const uint8_t** ptr
         } else { ptr[l] = o->dPyr + (size_t)frame * o->g.pyrFrameBytes + D.off; pitch[l] = D.pitch; }
         w[l] = D.w; h[l] = D.h; sf[l] = o->sf[l]; isf[l] = o->invsf[l];
     }
+    return ORBX_OK;
+}
+
+// internal (not part of include/orbx.h): where the batch's pyramids live, for the batched stereo matcher in the same library
+// (orbm_stereo_batch_async).  No sync: the caller orders its kernels behind the extraction on a stream.
+int orbx_internal_batch_layout(orbx_t* o, const uint8_t* const** l0tab, int* l0pitch, const uint8_t** pyr, size_t* frameBytes,
+                               int* nlevels, int* off, int* pitch, int* w, float* sf, float* isf, int* device, int* maxBatch, int* kpCap) {
+    if (!o || !o->curW) return ORBX_E_INVALID;
+    *l0tab = o->dL0Ptr; *l0pitch = o->lastL0Pitch ? o->lastL0Pitch : o->l0pitch; *pyr = o->dPyr; *frameBytes = o->g.pyrFrameBytes;
+    *nlevels = o->nlevels; *device = o->device; *maxBatch = o->maxBatch; *kpCap = o->g.kpCap;
+    for (int l = 0; l < o->nlevels; ++l) { const LevelDesc& D = o->g.lv[l]; off[l] = D.off; pitch[l] = D.pitch; w[l] = D.w; sf[l] = o->sf[l]; isf[l] = o->invsf[l]; }
     return ORBX_OK;
 }
 
