@@ -109,6 +109,27 @@ int orbm_search_by_projection_points(orbm_t*, const orbm_frame_t* f, const uint8
                                      const float* view_cos, const int32_t* level, const uint8_t* qdesc, const uint8_t* mp_obs,
                                      float th, float nnratio, int32_t* match);
 
+/* ---- frames resident in HBM.  Tracking runs 2-4 searches on the same Frame (TrackWithMotionModel / TrackReferenceKeyFrame,
+ * then SearchLocalPoints; Tracking.cc:3002-3211, 3867-3891): orbm_frame_create uploads keypoints, descriptors and mvuRight
+ * ONCE (space = ORBM_HOST), or adopts device arrays without copying them (space = ORBM_DEVICE: an extractor's result block,
+ * orbx_result_device -- they must stay valid while the frame lives), and builds the 64 x 48 grid (M14) on the device.  The
+ * *_resident searches then send only their queries and get back, per query, the candidate count and the 8 best (distance,
+ * visiting-order) candidates -- all the claim replay can look at unless every one of them is blocked, in which case the call
+ * falls back to the full candidate lists by itself.  Same arguments and results as M4 / M3 above. */
+typedef struct orbm_dframe orbm_dframe_t;
+int orbm_frame_create(orbm_t*, int space, int n, const orbm_kp_t* kps, const uint8_t* desc, const float* uright,
+                      float min_x, float min_y, float inv_w, float inv_h, orbm_dframe_t** out);
+void orbm_frame_destroy(orbm_dframe_t*);
+int orbm_frame_size(const orbm_dframe_t*);
+int orbm_search_by_projection_frame_resident(orbm_t*, const orbm_dframe_t* cur, const uint8_t* cur_blocked, const float* scale_factors,
+                                             int nq, const uint8_t* valid, const float* u, const float* v, const float* invzc,
+                                             const int32_t* octave, const float* angle, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                             float th, int forward, int backward, float mbf, int check_ori, int32_t* match);
+int orbm_search_by_projection_points_resident(orbm_t*, const orbm_dframe_t* f, const uint8_t* blocked, const float* scale_factors,
+                                              int nq, const uint8_t* in_view, const float* px, const float* py, const float* pxr,
+                                              const float* view_cos, const int32_t* level, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                              float th, float nnratio, int32_t* match);
+
 /* M5  ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:2723-2852), relocalisation.
  * valid[i] folds the caller-side gates (MapPoint present / not bad / not already found / projection in bounds /
  * distance invariance); level[i] = PredictScale; blocked[i2] = CurrentFrame.mvpMapPoints[i2] != NULL. */

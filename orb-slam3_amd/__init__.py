@@ -518,6 +518,44 @@ class FrameView:
                        self.grid_start.ctypes.data, self.grid_idx.ctypes.data)
 
 
+class ResidentFrame:
+    """A Frame kept in HBM across searches (include/orbm.h: orbm_frame_create).  `view` is a FrameView (host arrays are
+    uploaded once) or a dict of device pointers (kps, desc, n -- e.g. one frame of an extractor's result block, adopted in place)."""
+
+    def __init__(self, matcher, view=None, device=None, width=752, height=480, uright=None):
+        L = lib()
+        L.orbm_frame_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_void_p)]
+        L.orbm_frame_destroy.argtypes = [C.c_void_p]
+        L.orbm_frame_size.argtypes = [C.c_void_p]
+        rf = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8
+        L.orbm_search_by_projection_frame_resident.argtypes = rf + [C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.orbm_search_by_projection_points_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_float, C.c_float, C.c_void_p]
+        self.L, self.m = L, matcher
+        h = C.c_void_p()
+        if view is not None:
+            self.n = view.n
+            self._keep = view
+            _chk(L.orbm_frame_create(matcher.h, HOST, view.n, _p(view.kps), _p(view.desc), None if view.uright is None else _p(view.uright),
+                                     float(view.min_x), float(view.min_y), float(view.inv_w), float(view.inv_h), C.byref(h)), "orbm_frame_create")
+        else:
+            self.n = int(device["n"])
+            inv_w = np.float32(GRID_COLS) / np.float32(width); inv_h = np.float32(GRID_ROWS) / np.float32(height)
+            _chk(L.orbm_frame_create(matcher.h, DEVICE, self.n, device["kps"], device["desc"], uright, 0.0, 0.0, float(inv_w), float(inv_h), C.byref(h)),
+                 "orbm_frame_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orbm_frame_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def feature_vector_csr(node_of_feature):
     """DBoW2::FeatureVector (map<NodeId, vector<unsigned>>) as CSR: nodes ascending, features ascending inside."""
     node_of_feature = np.asarray(node_of_feature, np.int64)
@@ -553,6 +591,26 @@ class _SearchMixin:
                (qdesc, np.uint8), (mp_obs, np.uint8))]
         n = self._call("search_by_projection_frame", C.byref(cs), _p(arr[0]), _p(arr[1]), len(arr[2]), *[_p(a) for a in arr[2:]],
                        float(th), int(forward), int(backward), float(mbf), int(check_ori), _p(match))
+        return n, match
+
+    def SearchByProjectionFrameResident(self, cur, cur_blocked, scale_factors, valid, u, v, invzc, octave, angle, qdesc, mp_obs,
+                                        th, forward=False, backward=False, mbf=0.0, check_ori=True):
+        """M4 against a ResidentFrame: only the queries travel (include/orbm.h: orbm_search_by_projection_frame_resident)."""
+        match = np.full(cur.n, -1, np.int32)
+        arr = [np.ascontiguousarray(a, t) for a, t in ((cur_blocked, np.uint8), (scale_factors, np.float32), (valid, np.uint8),
+               (u, np.float32), (v, np.float32), (invzc, np.float32), (octave, np.int32), (angle, np.float32),
+               (qdesc, np.uint8), (mp_obs, np.uint8))]
+        n = self._call("search_by_projection_frame_resident", cur.h, _p(arr[0]), _p(arr[1]), len(arr[2]), *[_p(a) for a in arr[2:]],
+                       float(th), int(forward), int(backward), float(mbf), int(check_ori), _p(match))
+        return n, match
+
+    def SearchByProjectionPointsResident(self, f, blocked, scale_factors, in_view, px, py, pxr, view_cos, level, qdesc, mp_obs, th, nnratio):
+        match = np.full(f.n, -1, np.int32)
+        arr = [np.ascontiguousarray(a, t) for a, t in ((blocked, np.uint8), (scale_factors, np.float32), (in_view, np.uint8),
+               (px, np.float32), (py, np.float32), (pxr, np.float32), (view_cos, np.float32), (level, np.int32),
+               (qdesc, np.uint8), (mp_obs, np.uint8))]
+        n = self._call("search_by_projection_points_resident", f.h, _p(arr[0]), _p(arr[1]), len(arr[2]), *[_p(a) for a in arr[2:]],
+                       float(th), float(nnratio), _p(match))
         return n, match
 
     def SearchByProjectionPoints(self, f, blocked, scale_factors, in_view, px, py, pxr, view_cos, level, qdesc, mp_obs, th, nnratio):
@@ -705,7 +763,7 @@ def _install_search():
                                       C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     for name in ("grid_build", "SearchByProjectionFrame", "SearchByProjectionPoints", "SearchForInitialization",
                  "SearchForTriangulation", "SearchForTriangulationGated", "SearchByBoW", "SearchByProjectionKF", "SearchByBoWKF", "SearchByProjectionSim3", "Fuse", "SearchBySim3", "SearchByProjectionFrameFisheye",
-                 "SearchByProjectionPointsFisheye", "SearchByBoWFisheye", "_call"):
+                 "SearchByProjectionPointsFisheye", "SearchByBoWFisheye", "SearchByProjectionFrameResident", "SearchByProjectionPointsResident", "_call"):
         setattr(ORBmatcher, name, getattr(_SearchMixin, name))
     ORBmatcher._prefix = "orbm_"
 
@@ -804,6 +862,7 @@ def _frame_geometry_methods(prefix):
 
 
 EXPORTS += ["orbm_undistort_keypoints", "orbm_image_bounds", "orbm_is_in_frustum"]
+EXPORTS += ["orbm_frame_create", "orbm_frame_destroy", "orbm_frame_size", "orbm_search_by_projection_frame_resident", "orbm_search_by_projection_points_resident"]
 EXPORTS += ["orbm_grid_build", "orbm_window_candidates", "orbm_search_by_projection_frame", "orbm_search_by_projection_points",
             "orbm_search_for_initialization", "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_stereo_matches",
             "orbm_search_by_projection_kf", "orbm_search_by_bow_kf", "orbm_search_for_triangulation_legacy", "orbm_search_for_triangulation_gated",

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstring>
@@ -43,6 +44,16 @@ static hipError_t rec_time(orbm* m, hipEvent_t ev) {
     if (hipStreamIsCapturing(m->stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) return hipSuccess;
     return hipEventRecord(ev, m->stream);
 }
+
+// A frame kept in HBM across searches (orbm_frame_create): keypoints, descriptors, mvuRight and the 64 x 48 grid as CSR.
+struct orbm_dframe {
+    int device = 0, n = 0;
+    uint8_t* block = nullptr;                                  // owned allocation: [kps | desc | uright] (host-created frames) + [grid_start | grid_idx]
+    const KpIn* dKps = nullptr; const uint8_t* dDesc = nullptr; const float* dUr = nullptr;
+    int *dGs = nullptr, *dGi = nullptr;
+    std::vector<orbm_kp_t> hkps;                               // host copy: the replay reads angle / octave of the matched keypoint
+    float min_x = 0, min_y = 0, inv_w = 0, inv_h = 0;
+};
 
 namespace { int knn2_host(orbm* m, const uint8_t* q, int q_stride, const int32_t* nq, const uint8_t* t, int t_stride, const int32_t* nt,
                           int npairs, int32_t* idx2, int32_t* dist2); }
@@ -250,7 +261,7 @@ struct RotHist {                                             // rotation-consist
 // runs k_window for nq windows against frame f; candidate lists come back in host vectors
 int window_pass(orbm* m, const orbm_frame_t* f, int nq, const float* qx, const float* qy, const float* qr,
                 const int32_t* minl, const int32_t* maxl, const float* qur, const float* qer, const uint8_t* qdesc,
-                int& cap, std::vector<int>& cnt, std::vector<int>& idx, std::vector<int>& dist, bool retry = false) {
+                int& cap, std::vector<int>& cnt, std::vector<int>& idx, std::vector<int>& dist, bool retry = false, const orbm_dframe* df = nullptr) {
     // `cap` in: capacity of a window on the device; out: row stride of idx / dist (= the longest candidate list, >= 1)
     cnt.assign(nq, 0);
     if (nq == 0 || f->n == 0) return ORBM_OK;
@@ -258,10 +269,12 @@ int window_pass(orbm* m, const orbm_frame_t* f, int nq, const float* qx, const f
     MHIPCHK(hipSetDevice(m->device));
     DevBuf dk, dd, du, dgs, dgi, dqx, dqy, dqr, dmin, dmax, dqu, dqe, dqd, dcnt, didx, ddist, dovf, dpack;
     arena_reset(m);
-    UP(dk, f->kps, sizeof(KpIn) * f->n); UP(dd, f->desc, (size_t)32 * f->n);
-    if (f->uright) UP(du, f->uright, sizeof(float) * f->n);
-    UP(dgs, f->grid_start, sizeof(int) * (ORBM_GRID_COLS * ORBM_GRID_ROWS + 1));
-    UP(dgi, f->grid_idx, sizeof(int) * f->n);
+    if (!df) {                                                  // host frame: it travels with every call (a resident frame does not)
+        UP(dk, f->kps, sizeof(KpIn) * f->n); UP(dd, f->desc, (size_t)32 * f->n);
+        if (f->uright) UP(du, f->uright, sizeof(float) * f->n);
+        UP(dgs, f->grid_start, sizeof(int) * (ORBM_GRID_COLS * ORBM_GRID_ROWS + 1));
+        UP(dgi, f->grid_idx, sizeof(int) * f->n);
+    }
     UP(dqx, qx, sizeof(float) * nq); UP(dqy, qy, sizeof(float) * nq); UP(dqr, qr, sizeof(float) * nq);
     UP(dmin, minl, sizeof(int) * nq); UP(dmax, maxl, sizeof(int) * nq);
     if (qur) UP(dqu, qur, sizeof(float) * nq);
@@ -273,8 +286,9 @@ int window_pass(orbm* m, const orbm_frame_t* f, int nq, const float* qx, const f
     MHIPCHK(hipMemsetAsync(dovf.ptr(), 0, sizeof(int), m->stream));
     MHIPCHK(rec_time(m, m->e0));
     ARENA_FLUSH(m);
-    hipLaunchKernelGGL(k_window, dim3((nq + 3) / 4), dim3(256), 0, m->stream, dk.as<KpIn>(), dd.as<uint8_t>(),
-                       f->uright ? du.as<float>() : nullptr, dgs.as<int>(), dgi.as<int>(), f->min_x, f->min_y, f->inv_w, f->inv_h,
+    hipLaunchKernelGGL(k_window, dim3((nq + 3) / 4), dim3(256), 0, m->stream, df ? df->dKps : dk.as<KpIn>(), df ? df->dDesc : dd.as<uint8_t>(),
+                       df ? (f->uright ? df->dUr : nullptr) : (f->uright ? du.as<float>() : nullptr), df ? df->dGs : dgs.as<int>(), df ? df->dGi : dgi.as<int>(),
+                       f->min_x, f->min_y, f->inv_w, f->inv_h,
                        nq, dqx.as<float>(), dqy.as<float>(), dqr.as<float>(), dmin.as<int>(), dmax.as<int>(),
                        qur ? dqu.as<float>() : nullptr, qer ? dqe.as<float>() : nullptr, dqd.as<uint8_t>(), cap,
                        dcnt.as<int>(), didx.as<int>(), ddist.as<int>(), dovf.as<int>());
@@ -305,12 +319,54 @@ int window_pass(orbm* m, const orbm_frame_t* f, int nq, const float* qx, const f
         // frames, the 100-px initialisation window) is simply run again with room for every keypoint of the frame
         if (devCap < f->n) {
             cap = f->n;
-            return window_pass(m, f, nq, qx, qy, qr, minl, maxl, qur, qer, qdesc, cap, cnt, idx, dist, true);
+            return window_pass(m, f, nq, qx, qy, qr, minl, maxl, qur, qer, qdesc, cap, cnt, idx, dist, true, df);
         }
         set_merr("a search window returned more than %d candidates", devCap);
         return ORBM_E_CAPACITY;
     }
     cap = std::max(maxc, 1);
+    return ORBM_OK;
+}
+
+// k_window_topk against a resident frame: per window the candidate count and the WT_K smallest (distance, position) keys.
+// One upload of the queries, one kernel, one download.
+int window_topk_pass(orbm* m, const orbm_dframe* df, bool stereo_gate, int nq, const float* qx, const float* qy, const float* qr,
+                     const int32_t* minl, const int32_t* maxl, const float* qur, const float* qer, const uint8_t* qdesc,
+                     const int** cnt, const unsigned int** keys) {
+    // results stay in the arena's pinned mirror (valid until the handle's next call): *cnt [nq], *keys [nq][WT_K]
+    *cnt = nullptr; *keys = nullptr;
+    if (nq == 0 || df->n == 0) return ORBM_OK;
+    MHIPCHK(hipSetDevice(m->device));
+    DevBuf dqx, dqy, dqr, dmin, dmax, dqu, dqe, dqd, dcnt, dkeys;
+    arena_reset(m);
+    UP(dqx, qx, sizeof(float) * nq); UP(dqy, qy, sizeof(float) * nq); UP(dqr, qr, sizeof(float) * nq);
+    UP(dmin, minl, sizeof(int) * nq); UP(dmax, maxl, sizeof(int) * nq);
+    if (qur) UP(dqu, qur, sizeof(float) * nq);
+    if (qer) UP(dqe, qer, sizeof(float) * nq);
+    UP(dqd, qdesc, (size_t)32 * nq);
+    AL(dcnt, sizeof(int) * nq); AL(dkeys, sizeof(unsigned int) * (size_t)nq * WT_K);
+    static const bool prof = getenv("ORBM_PROFILE") != nullptr;
+    static const bool copies = getenv("ORBM_TOPK_COPIES") != nullptr;     // A/B: staged copies instead of zero-copy
+    auto T = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = prof ? T() : 0;
+    if (prof) MHIPCHK(rec_time(m, m->e0));                       // a latency path: no event records unless someone is looking
+    // Zero-copy: the queries sit in the arena's pinned host mirror, which the GPU can address; the kernel reads them over PCIe
+    // and writes counts and keys straight back into it.  ~110 KB in all: two copy commands would cost more in latency (~10 us
+    // each) than the link takes to move the bytes, and this is a latency path (Tracking waits for the result).
+    auto hp = [&](DevBuf& b) { return (void*)(m->arPin + b.off); };
+    if (copies) ARENA_FLUSH(m);
+#define QP(buf, T_) (copies ? (buf).as<T_>() : (T_*)hp(buf))
+    hipLaunchKernelGGL(k_window_topk, dim3((nq + 3) / 4), dim3(256), 0, m->stream, df->dKps, df->dDesc, stereo_gate ? df->dUr : nullptr, df->dGs, df->dGi,
+                       df->min_x, df->min_y, df->inv_w, df->inv_h, nq, QP(dqx, float), QP(dqy, float), QP(dqr, float), QP(dmin, int), QP(dmax, int),
+                       qur ? QP(dqu, float) : nullptr, qer ? QP(dqe, float) : nullptr, QP(dqd, uint8_t), QP(dcnt, int), QP(dkeys, unsigned int));
+#undef QP
+    if (prof) { MHIPCHK(rec_time(m, m->e1)); m->timed = true; }
+    MHIPCHK(hipGetLastError());
+    if (copies) MHIPCHK(hipMemcpyAsync(m->arPin + m->arOutLo, m->arDev + m->arOutLo, m->arOutHi - m->arOutLo, hipMemcpyDeviceToHost, m->stream));
+    const double t1 = prof ? T() : 0;
+    MHIPCHK(hipStreamSynchronize(m->stream));
+    if (prof) fprintf(stderr, "orbm profile:   enqueue %.1f us, wait %.1f us (%s)\n", t1 - t0, T() - t1, copies ? "staged copies" : "zero-copy");
+    *cnt = (const int*)dcnt.host(); *keys = (const unsigned int*)dkeys.host();
     return ORBM_OK;
 }
 
@@ -389,11 +445,23 @@ int orbm_window_candidates(orbm_t* m, const orbm_frame_t* f, int nq, const float
     return rc;
 }
 
-int orbm_search_by_projection_frame(orbm_t* m, const orbm_frame_t* cur, const uint8_t* cur_blocked, const float* sf,
-                                    int nq, const uint8_t* valid, const float* u, const float* v, const float* invzc,
-                                    const int32_t* octave, const float* angle, const uint8_t* qdesc, const uint8_t* mp_obs,
-                                    float th, int bForward, int bBackward, float mbf, int check_ori, int32_t* match) {
-    if (!m || !cur || nq < 0) return ORBM_E_INVALID;
+// Candidate lists as the claim replays see them: either the full [queries][stride] lists of window_pass, or the K best
+// (distance, position) keys of window_topk_pass, which are a prefix of the list in exactly the order that matters to a
+// `dist < bestDist` scan (see k_window_topk).  trunc(i): the list of query i was cut.
+struct CandLists {
+    const int* cnt = nullptr; const int* idx = nullptr; const int* dist = nullptr; int stride = 0;
+    const unsigned int* keys = nullptr;                                 // dist << 20 | keypoint index, in (distance, visiting order) rank
+    int count(int i) const { return keys ? std::min(cnt[i], (int)WT_K) : cnt[i]; }
+    bool trunc(int i) const { return keys && cnt[i] > WT_K; }
+    int index(int i, int c) const { return keys ? (int)(keys[(size_t)i * WT_K + c] & 0xFFFFFu) : idx[(size_t)i * stride + c]; }
+    int distance(int i, int c) const { return keys ? (int)(keys[(size_t)i * WT_K + c] >> 20) : dist[(size_t)i * stride + c]; }
+};
+
+// M4 body.  cur: the frame's view (host arrays, or the resident frame's host-side copy of what the replay reads); df: resident frame or NULL
+static int search_by_projection_frame_impl(orbm_t* m, const orbm_frame_t* cur, const orbm_dframe* df, const uint8_t* cur_blocked, const float* sf,
+                                           int nq, const uint8_t* valid, const float* u, const float* v, const float* invzc,
+                                           const int32_t* octave, const float* angle, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                           float th, int bForward, int bBackward, float mbf, int check_ori, int32_t* match) {
     // windows exactly as ORBmatcher.cc:2543-2549; invalid queries get an empty window (r < 0)
     std::vector<float> qr(nq), qur(nq), qer(nq);
     std::vector<int> minl(nq), maxl(nq);
@@ -408,47 +476,77 @@ int orbm_search_by_projection_frame(orbm_t* m, const orbm_frame_t* cur, const ui
         qur[i] = u[i] - mbf * invzc[i];                                    // :2571
         qer[i] = cur->uright ? radius : -1.f;
     }
-    int cap = std::max(1, std::min(cur->n, 2048));      // becomes the row stride of idx / dist after window_pass
-    std::vector<int> cnt, idx, dist;
-    int rc = window_pass(m, cur, nq, u, v, qr.data(), minl.data(), maxl.data(), qur.data(), qer.data(), qdesc, cap, cnt, idx, dist);
-    if (rc) return rc;
-    // sequential replay of the claims (ORBmatcher.cc:2553-2612)
+    // sequential replay of the claims (ORBmatcher.cc:2553-2612); false = a cut list ran out of unblocked candidates
     int nmatches = 0;
-    RotHist rh;
-    const float factor = ORBM_HISTO_LENGTH / 360.0f;
-    std::vector<uint8_t> blocked(cur_blocked, cur_blocked + cur->n);
-    for (int i = 0; i < cur->n; ++i) match[i] = -1;
-    for (int i = 0; i < nq; ++i) {
-        if (!valid[i] || cnt[i] == 0) continue;
-        int bestDist = 256, bestIdx2 = -1;
-        for (int c = 0; c < cnt[i]; ++c) {
-            const int i2 = idx[(size_t)i * cap + c];
-            if (blocked[i2]) continue;
-            const int d = dist[(size_t)i * cap + c];
-            if (d < bestDist) { bestDist = d; bestIdx2 = i2; }
+    auto replay = [&](const CandLists& Lc) -> bool {
+        nmatches = 0;
+        RotHist rh;
+        const float factor = ORBM_HISTO_LENGTH / 360.0f;
+        std::vector<uint8_t> blocked(cur_blocked, cur_blocked + cur->n);
+        for (int i = 0; i < cur->n; ++i) match[i] = -1;
+        for (int i = 0; i < nq; ++i) {
+            const int nc = valid[i] ? Lc.count(i) : 0;
+            if (nc == 0) continue;
+            int bestDist = 256, bestIdx2 = -1;
+            for (int c = 0; c < nc; ++c) {
+                const int i2 = Lc.index(i, c);
+                if (blocked[i2]) continue;
+                const int d = Lc.distance(i, c);
+                if (d < bestDist) { bestDist = d; bestIdx2 = i2; }
+            }
+            if (bestIdx2 < 0 && Lc.trunc(i)) return false;
+            if (bestDist <= ORBM_TH_HIGH) {
+                match[bestIdx2] = i;
+                if (mp_obs[i]) blocked[bestIdx2] = 1;
+                nmatches++;
+                if (check_ori) rh.add(angle[i], cur->kps[bestIdx2].angle, factor, bestIdx2);
+            }
         }
-        if (bestDist <= ORBM_TH_HIGH) {
-            match[bestIdx2] = i;
-            if (mp_obs[i]) blocked[bestIdx2] = 1;
-            nmatches++;
-            if (check_ori) rh.add(angle[i], cur->kps[bestIdx2].angle, factor, bestIdx2);
+        if (check_ori) {
+            int ind[3];
+            rh.maxima(ind);
+            for (int b = 0; b < ORBM_HISTO_LENGTH; ++b)
+                if (b != ind[0] && b != ind[1] && b != ind[2])
+                    for (int k : rh.bins[b]) { match[k] = ORBM_MATCH_PRUNED; nmatches--; }
         }
+        return true;
+    };
+    std::vector<int> cnt, idx, dist;
+    if (df) {
+        const int* kc = nullptr; const unsigned int* kk = nullptr;
+        static const bool prof = getenv("ORBM_PROFILE") != nullptr;
+        auto T = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = prof ? T() : 0;
+        int rc = window_topk_pass(m, df, cur->uright != nullptr, nq, u, v, qr.data(), minl.data(), maxl.data(), qur.data(), qer.data(), qdesc, &kc, &kk);
+        if (rc) return rc;
+        const double t1 = prof ? T() : 0;
+        CandLists Lk; Lk.cnt = kc; Lk.keys = kk;
+        const bool done = !kc || replay(Lk);
+        if (!kc) { for (int i = 0; i < cur->n; ++i) match[i] = -1; nmatches = 0; }
+        if (prof) fprintf(stderr, "orbm profile: top-K pass %.1f us, replay %.1f us%s\n", t1 - t0, T() - t1, done ? "" : " (fallback)");
+        if (done) return nmatches;
     }
-    if (check_ori) {
-        int ind[3];
-        rh.maxima(ind);
-        for (int b = 0; b < ORBM_HISTO_LENGTH; ++b)
-            if (b != ind[0] && b != ind[1] && b != ind[2])
-                for (int k : rh.bins[b]) { match[k] = ORBM_MATCH_PRUNED; nmatches--; }
-    }
+    int cap = std::max(1, std::min(cur->n, 2048));      // becomes the row stride of idx / dist after window_pass
+    int rc = window_pass(m, cur, nq, u, v, qr.data(), minl.data(), maxl.data(), qur.data(), qer.data(), qdesc, cap, cnt, idx, dist, false, df);
+    if (rc) return rc;
+    CandLists Lf; Lf.cnt = cnt.data(); Lf.idx = idx.data(); Lf.dist = dist.data(); Lf.stride = cap;
+    replay(Lf);
     return nmatches;
 }
 
-int orbm_search_by_projection_points(orbm_t* m, const orbm_frame_t* f, const uint8_t* blocked_in, const float* sf,
-                                     int nq, const uint8_t* in_view, const float* px, const float* py, const float* pxr,
-                                     const float* view_cos, const int32_t* level, const uint8_t* qdesc, const uint8_t* mp_obs,
-                                     float th, float nnratio, int32_t* match) {
-    if (!m || !f || nq < 0) return ORBM_E_INVALID;
+int orbm_search_by_projection_frame(orbm_t* m, const orbm_frame_t* cur, const uint8_t* cur_blocked, const float* sf,
+                                    int nq, const uint8_t* valid, const float* u, const float* v, const float* invzc,
+                                    const int32_t* octave, const float* angle, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                    float th, int bForward, int bBackward, float mbf, int check_ori, int32_t* match) {
+    if (!m || !cur || nq < 0) return ORBM_E_INVALID;
+    return search_by_projection_frame_impl(m, cur, nullptr, cur_blocked, sf, nq, valid, u, v, invzc, octave, angle, qdesc, mp_obs, th, bForward, bBackward, mbf,
+                                           check_ori, match);
+}
+
+static int search_by_projection_points_impl(orbm_t* m, const orbm_frame_t* f, const orbm_dframe* df, const uint8_t* blocked_in, const float* sf,
+                                            int nq, const uint8_t* in_view, const float* px, const float* py, const float* pxr,
+                                            const float* view_cos, const int32_t* level, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                            float th, float nnratio, int32_t* match) {
     const bool bFactor = th != 1.0;
     std::vector<float> qr(nq), qer(nq);
     std::vector<int> minl(nq), maxl(nq);
@@ -460,33 +558,140 @@ int orbm_search_by_projection_points(orbm_t* m, const orbm_frame_t* f, const uin
         minl[i] = level[i] - 1; maxl[i] = level[i];
         qer[i] = f->uright ? r * sf[level[i]] : -1.f;                      // :107-117
     }
-    int cap = std::max(1, std::min(f->n, 2048));      // becomes the row stride of idx / dist after window_pass
-    std::vector<int> cnt, idx, dist;
-    int rc = window_pass(m, f, nq, px, py, qr.data(), minl.data(), maxl.data(), pxr, qer.data(), qdesc, cap, cnt, idx, dist);
-    if (rc) return rc;
     int nmatches = 0;
-    std::vector<uint8_t> blocked(blocked_in, blocked_in + f->n);
-    for (int i = 0; i < f->n; ++i) match[i] = -1;
-    for (int iMP = 0; iMP < nq; ++iMP) {
-        if (!in_view[iMP] || cnt[iMP] == 0) continue;
-        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
-        for (int c = 0; c < cnt[iMP]; ++c) {
-            const int k = idx[(size_t)iMP * cap + c];
-            if (blocked[k]) continue;
-            const int d = dist[(size_t)iMP * cap + c];
-            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = f->kps[k].octave; bestIdx = k; }
-            else if (d < bestDist2) { bestLevel2 = f->kps[k].octave; bestDist2 = d; }
-        }
-        if (bestDist <= ORBM_TH_HIGH) {
-            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
-            if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
-                match[bestIdx] = iMP;
-                if (mp_obs[iMP]) blocked[bestIdx] = 1;
-                nmatches++;
+    auto replay = [&](const CandLists& Lc) -> bool {
+        nmatches = 0;
+        std::vector<uint8_t> blocked(blocked_in, blocked_in + f->n);
+        for (int i = 0; i < f->n; ++i) match[i] = -1;
+        for (int iMP = 0; iMP < nq; ++iMP) {
+            const int nc = in_view[iMP] ? Lc.count(iMP) : 0;
+            if (nc == 0) continue;
+            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1, seen = 0;
+            for (int c = 0; c < nc; ++c) {
+                const int k = Lc.index(iMP, c);
+                if (blocked[k]) continue;
+                ++seen;
+                const int d = Lc.distance(iMP, c);
+                if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = f->kps[k].octave; bestIdx = k; }
+                else if (d < bestDist2) { bestLevel2 = f->kps[k].octave; bestDist2 = d; }
+            }
+            if (seen < 2 && Lc.trunc(iMP)) return false;                    // best AND second must come from the unblocked candidates
+            if (bestDist <= ORBM_TH_HIGH) {
+                if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+                if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                    match[bestIdx] = iMP;
+                    if (mp_obs[iMP]) blocked[bestIdx] = 1;
+                    nmatches++;
+                }
             }
         }
+        return true;
+    };
+    std::vector<int> cnt, idx, dist;
+    if (df) {
+        const int* kc = nullptr; const unsigned int* kk = nullptr;
+        int rc = window_topk_pass(m, df, f->uright != nullptr, nq, px, py, qr.data(), minl.data(), maxl.data(), pxr, qer.data(), qdesc, &kc, &kk);
+        if (rc) return rc;
+        if (!kc) { for (int i = 0; i < f->n; ++i) match[i] = -1; return 0; }
+        CandLists Lk; Lk.cnt = kc; Lk.keys = kk;
+        if (replay(Lk)) return nmatches;
     }
+    int cap = std::max(1, std::min(f->n, 2048));      // becomes the row stride of idx / dist after window_pass
+    int rc = window_pass(m, f, nq, px, py, qr.data(), minl.data(), maxl.data(), pxr, qer.data(), qdesc, cap, cnt, idx, dist, false, df);
+    if (rc) return rc;
+    CandLists Lf; Lf.cnt = cnt.data(); Lf.idx = idx.data(); Lf.dist = dist.data(); Lf.stride = cap;
+    replay(Lf);
     return nmatches;
+}
+
+int orbm_search_by_projection_points(orbm_t* m, const orbm_frame_t* f, const uint8_t* blocked_in, const float* sf,
+                                     int nq, const uint8_t* in_view, const float* px, const float* py, const float* pxr,
+                                     const float* view_cos, const int32_t* level, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                     float th, float nnratio, int32_t* match) {
+    if (!m || !f || nq < 0) return ORBM_E_INVALID;
+    return search_by_projection_points_impl(m, f, nullptr, blocked_in, sf, nq, in_view, px, py, pxr, view_cos, level, qdesc, mp_obs, th, nnratio, match);
+}
+
+// ---- frames resident in HBM: what Tracking's 2-4 searches per frame work on (Tracking.cc:3002-3211, 3867-3891) ----
+void orbm_frame_destroy(orbm_dframe_t* f) {
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    if (f->block) (void)hipFree(f->block);
+    delete f;
+}
+
+int orbm_frame_create(orbm_t* m, int space, int n, const orbm_kp_t* kps, const uint8_t* desc, const float* uright,
+                      float min_x, float min_y, float inv_w, float inv_h, orbm_dframe_t** out) {
+    if (!m || !out || n < 0 || (n > 0 && (!kps || !desc))) return ORBM_E_INVALID;
+    *out = nullptr;
+    if (n > 65535) { set_merr("a resident frame holds at most 65535 keypoints"); return ORBM_E_CAPACITY; }
+    int n2 = 64; while (n2 < n) n2 <<= 1;
+    if ((size_t)n2 * 4 > 150 * 1024) { set_merr("too many keypoints for the LDS sort"); return ORBM_E_CAPACITY; }
+    MHIPCHK(hipSetDevice(m->device));
+    orbm_dframe* f = new orbm_dframe;
+    f->device = m->device; f->n = n; f->min_x = min_x; f->min_y = min_y; f->inv_w = inv_w; f->inv_h = inv_h;
+    const size_t ncells = ORBM_GRID_COLS * ORBM_GRID_ROWS + 1;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t bKps = space == ORBM_HOST ? al(sizeof(KpIn) * (size_t)std::max(n, 1)) : 0, bDesc = space == ORBM_HOST ? al((size_t)32 * std::max(n, 1)) : 0,
+                 bUr = space == ORBM_HOST && uright ? al(sizeof(float) * (size_t)std::max(n, 1)) : 0, bGs = al(sizeof(int) * ncells), bGi = al(sizeof(int) * (size_t)(n + 1)) + 256;
+    if (hipMalloc((void**)&f->block, bKps + bDesc + bUr + bGs + bGi) != hipSuccess) { set_merr("hipMalloc failed"); delete f; return ORBM_E_HIP; }
+    uint8_t* p = f->block;
+    f->hkps.resize(std::max(n, 1));
+    hipError_t e = hipSuccess;
+    if (space == ORBM_HOST) {
+        f->dKps = (const KpIn*)p; p += bKps; f->dDesc = p; p += bDesc;
+        if (uright) { f->dUr = (const float*)p; p += bUr; }
+        if (n > 0) {
+            memcpy(f->hkps.data(), kps, sizeof(orbm_kp_t) * n);
+            e = hipMemcpyAsync((void*)f->dKps, kps, sizeof(KpIn) * n, hipMemcpyHostToDevice, m->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync((void*)f->dDesc, desc, (size_t)32 * n, hipMemcpyHostToDevice, m->stream);
+            if (e == hipSuccess && uright) e = hipMemcpyAsync((void*)f->dUr, uright, sizeof(float) * n, hipMemcpyHostToDevice, m->stream);
+        }
+    } else {                                                     // adopt the caller's device arrays (an extractor's result block): no copy of them
+        f->dKps = (const KpIn*)kps; f->dDesc = desc; f->dUr = uright;
+        if (n > 0) e = hipMemcpyAsync(f->hkps.data(), kps, sizeof(orbm_kp_t) * n, hipMemcpyDeviceToHost, m->stream);
+    }
+    f->dGs = (int*)p; p += bGs; f->dGi = (int*)p;
+    int* dPlaced = f->dGi + (n + 1);
+    if (e == hipSuccess && n > 0) {
+        if (n2 * 4 > 48 * 1024) e = hipFuncSetAttribute((const void*)k_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 4);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), (size_t)n2 * 4, m->stream, f->dKps, n, n2, min_x, min_y, inv_w, inv_h, f->dGs, f->dGi, dPlaced);
+            e = hipGetLastError();
+        }
+    } else if (e == hipSuccess) e = hipMemsetAsync(f->dGs, 0, sizeof(int) * ncells, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    if (e != hipSuccess) { set_merr("resident frame setup failed: %s", hipGetErrorString(e)); orbm_frame_destroy(f); return ORBM_E_HIP; }
+    *out = f;
+    return ORBM_OK;
+}
+
+int orbm_frame_size(const orbm_dframe_t* f) { return f ? f->n : ORBM_E_INVALID; }
+
+static orbm_frame_t resident_view(const orbm_dframe* f, bool stereo_gate) {
+    orbm_frame_t v;
+    v.n = f->n; v.kps = f->hkps.data(); v.desc = nullptr; v.uright = stereo_gate && f->dUr ? (const float*)f->hkps.data() /* non-NULL marker: only tested, never read */ : nullptr;
+    v.min_x = f->min_x; v.min_y = f->min_y; v.inv_w = f->inv_w; v.inv_h = f->inv_h; v.grid_start = nullptr; v.grid_idx = nullptr;
+    return v;
+}
+
+int orbm_search_by_projection_frame_resident(orbm_t* m, const orbm_dframe_t* cur, const uint8_t* cur_blocked, const float* sf,
+                                             int nq, const uint8_t* valid, const float* u, const float* v, const float* invzc,
+                                             const int32_t* octave, const float* angle, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                             float th, int bForward, int bBackward, float mbf, int check_ori, int32_t* match) {
+    if (!m || !cur || nq < 0 || cur->device != m->device) return ORBM_E_INVALID;
+    const orbm_frame_t view = resident_view(cur, true);
+    return search_by_projection_frame_impl(m, &view, cur, cur_blocked, sf, nq, valid, u, v, invzc, octave, angle, qdesc, mp_obs, th, bForward, bBackward, mbf,
+                                           check_ori, match);
+}
+
+int orbm_search_by_projection_points_resident(orbm_t* m, const orbm_dframe_t* f, const uint8_t* blocked_in, const float* sf,
+                                              int nq, const uint8_t* in_view, const float* px, const float* py, const float* pxr,
+                                              const float* view_cos, const int32_t* level, const uint8_t* qdesc, const uint8_t* mp_obs,
+                                              float th, float nnratio, int32_t* match) {
+    if (!m || !f || nq < 0 || f->device != m->device) return ORBM_E_INVALID;
+    const orbm_frame_t view = resident_view(f, true);
+    return search_by_projection_points_impl(m, &view, f, blocked_in, sf, nq, in_view, px, py, pxr, view_cos, level, qdesc, mp_obs, th, nnratio, match);
 }
 
 int orbm_search_for_initialization(orbm_t* m, const orbm_frame_t* F1, const orbm_frame_t* F2, float* prev, int windowSize,

@@ -366,6 +366,107 @@ __global__ __launch_bounds__(256) void k_window(const KpIn* __restrict__ kps, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_window_topk: the same windows, but only what the sequential claim replay of the projection searches can ever look at
+// comes back: per window the WT_K candidates with the smallest (distance, position in the reference's visiting order) and
+// the candidate count.  The replay takes the first (M4, M5) or the first two (M3: best and second) candidates that are not
+// blocked in that order -- exactly the order in which `dist < bestDist` / `else if dist < bestDist2` would have met them --
+// so unless every returned candidate of a longer list is blocked, the full [windows][capacity] lists never leave the GPU.
+// key = dist << 40 | position << 20 | keypoint index; the running top-K lives in wave-uniform registers.
+// ------------------------------------------------------------------------------------------------
+#define WT_K 8
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, o), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o);
+        const u64 w = (u64)lo | ((u64)hi << 32);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+__global__ __launch_bounds__(256) void k_window_topk(const KpIn* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                     const float* __restrict__ uright, const int* __restrict__ gs,
+                                                     const int* __restrict__ gi, float min_x, float min_y, float inv_w, float inv_h,
+                                                     int nq, const float* __restrict__ qx, const float* __restrict__ qy,
+                                                     const float* __restrict__ qr, const int* __restrict__ qminl,
+                                                     const int* __restrict__ qmaxl, const float* __restrict__ qur,
+                                                     const float* __restrict__ qer, const uint8_t* __restrict__ qdesc,
+                                                     int* __restrict__ out_cnt, unsigned int* __restrict__ out_keys) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const float x = qx[q], y = qy[q], r = qr[q];
+    const int minLevel = qminl[q], maxLevel = qmaxl[q];
+    const u64 INV = ~0ull;
+    u64 top[WT_K];
+#pragma unroll
+    for (int i = 0; i < WT_K; ++i) top[i] = INV;
+    int cnt = 0;
+    const int nMinCellX = max(0, (int)floorf((x - min_x - r) * inv_w));
+    const int nMaxCellX = min(63, (int)ceilf((x - min_x + r) * inv_w));
+    const int nMinCellY = max(0, (int)floorf((y - min_y - r) * inv_h));
+    const int nMaxCellY = min(47, (int)ceilf((y - min_y + r) * inv_h));
+    if (r >= 0 && nMinCellX < 64 && nMaxCellX >= 0 && nMinCellY < 48 && nMaxCellY >= 0) {
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        const uint4* qp = (const uint4*)(qdesc + (size_t)q * 32);
+        const uint4 qlo = qp[0], qhi = qp[1];
+        const u64 a[4] = {(u64)qlo.x | ((u64)qlo.y << 32), (u64)qlo.z | ((u64)qlo.w << 32),
+                          (u64)qhi.x | ((u64)qhi.y << 32), (u64)qhi.z | ((u64)qhi.w << 32)};
+        const float er = qer ? qer[q] : -1.f, ur = qur ? qur[q] : 0.f;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int ix = nMinCellX; ix <= nMaxCellX; ++ix) {
+            const int j0 = gs[ix * 48 + nMinCellY], j1 = gs[ix * 48 + nMaxCellY + 1];
+            for (int jb = j0; jb < j1; jb += 64) {
+                const int j = jb + lane;
+                bool ok = false;
+                int k = 0;
+                if (j < j1) {
+                    k = gi[j];
+                    const KpIn kp = kps[k];
+                    ok = true;
+                    if (bCheckLevels) {
+                        if (kp.octave < minLevel) ok = false;
+                        if (maxLevel >= 0 && kp.octave > maxLevel) ok = false;
+                    }
+                    const float distx = kp.x - x, disty = kp.y - y;
+                    if (!(fabsf(distx) < r && fabsf(disty) < r)) ok = false;
+                    if (ok && er >= 0.f && uright) {
+                        const float urk = uright[k];
+                        if (urk > 0 && fabsf(ur - urk) > er) ok = false;
+                    }
+                }
+                const unsigned long long bal = __ballot(ok);
+                u64 key = INV;
+                if (ok) {
+                    const int pos = cnt + __popcll(bal & lt);
+                    const uint4* tp = (const uint4*)(desc + (size_t)k * 32);
+                    const uint4 lo = tp[0], hi = tp[1];
+                    const int d = ham256(a, (u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
+                                         (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32));
+                    key = ((u64)d << 40) | ((u64)pos << 20) | (u64)k;
+                }
+                cnt += __popcll(bal);
+                if (bal == 0) continue;
+                // merge this chunk into the running top-K: pull its minima one by one until one no longer beats the K-th
+                for (int rnd = 0; rnd < WT_K; ++rnd) {
+                    const u64 m = wave_min_u64(key);
+                    if (m >= top[WT_K - 1]) break;               // INV included
+                    if (key == m) key = INV;                     // keys are unique (position)
+                    u64 c = m;
+#pragma unroll
+                    for (int i = 0; i < WT_K; ++i) { const u64 t = top[i]; const bool sw = c < t; top[i] = sw ? c : t; c = sw ? t : c; }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        out_cnt[q] = cnt;
+#pragma unroll
+        for (int i = 0; i < WT_K; ++i)                            // the array position carries the (distance, visiting order) rank: 32 bits suffice
+            out_keys[(size_t)q * WT_K + i] = top[i] == INV ? 0xFFFFFFFFu : (unsigned)((top[i] >> 40) << 20) | (unsigned)(top[i] & 0xFFFFFu);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_pairdist: Hamming distances for a job list (bucket joins of SearchByBoW / SearchForTriangulation_).
 // job j: query row q1[j] of set 1 against rows idx2[l2[j] .. l2[j]+len[j]) of set 2, outputs at off[j]...
 // One thread per output element (the job is found by binary search in the output offsets).

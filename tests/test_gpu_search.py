@@ -414,3 +414,62 @@ def test_pruned_slots_are_marked(pkg, scene):
     n_ref, m_ref = scene["OM"].SearchByProjectionFrame(views[1], **args)
     assert n_gpu == n_ref and np.array_equal(m_gpu, m_ref)
     assert (m_ref == -2).sum() > 10 and (m_ref >= 0).sum() == n_ref
+
+
+@pytest.mark.parametrize("th,fwd,bwd,stereo,ori,pblock", [(15, 0, 0, False, True, 0.05), (7, 0, 0, True, True, 0.05), (7, 1, 0, True, False, 0.3),
+                                                           (30, 0, 0, False, True, 0.97), (7, 0, 1, True, True, 0.6)])
+def test_resident_frame_search_by_projection_frame(pkg, scene, th, fwd, bwd, stereo, ori, pblock):
+    """M4 against a frame kept in HBM: only the queries travel and only the 8 best candidates per query come back; the claim
+    replay must still equal the oracle's -- also when most slots are blocked, so that cut lists run dry and the call falls
+    back to the full candidate lists by itself (pblock 0.97)."""
+    rng = np.random.default_rng(th * 11 + fwd + 2 * bwd)
+    kr = scene["kr"]
+    ur = np.where(rng.random(len(kr)) < 0.6, kr["x"] - rng.uniform(2, 40, len(kr)), -1).astype(np.float32) if stereo else None
+    view = pkg.FrameView(kr, scene["dr"], 752, 480, uright=ur, backend=scene["OM"])
+    res = pkg.ResidentFrame(scene["m"], view)
+    n, u, v = _queries(scene, rng)
+    args = dict(cur_blocked=rng.random(len(kr)) < pblock, scale_factors=scene["sf"], valid=rng.random(n) < 0.85, u=u, v=v,
+                invzc=rng.uniform(0.05, 1.0, n), octave=scene["kl"]["octave"], angle=scene["kl"]["angle"], qdesc=scene["dl"],
+                mp_obs=rng.random(n) < 0.9, th=th, forward=bool(fwd), backward=bool(bwd), mbf=47.9, check_ori=ori)
+    n_gpu, m_gpu = scene["m"].SearchByProjectionFrameResident(res, **args)
+    n_ref, m_ref = scene["OM"].SearchByProjectionFrame(view, **args)
+    assert n_gpu == n_ref and np.array_equal(m_gpu, m_ref)
+    res.close()
+
+
+@pytest.mark.parametrize("th,nnratio,stereo,pblock", [(1.0, 0.8, False, 0.05), (3.0, 0.8, True, 0.05), (5.0, 0.9, False, 0.9), (8.0, 0.9, True, 0.5)])
+def test_resident_frame_search_by_projection_points(pkg, scene, th, nnratio, stereo, pblock):
+    rng = np.random.default_rng(int(th * 10) + 1)
+    kr = scene["kr"]
+    ur = np.where(rng.random(len(kr)) < 0.6, kr["x"] - rng.uniform(2, 40, len(kr)), -1).astype(np.float32) if stereo else None
+    view = pkg.FrameView(kr, scene["dr"], 752, 480, uright=ur, backend=scene["OM"])
+    res = pkg.ResidentFrame(scene["m"], view)
+    n, u, v = _queries(scene, rng, jitter=2.0)
+    args = dict(blocked=rng.random(len(kr)) < pblock, scale_factors=scene["sf"], in_view=rng.random(n) < 0.8, px=u, py=v,
+                pxr=(u - rng.uniform(2, 40, n)).astype(np.float32), view_cos=rng.uniform(0.99, 1.0, n),
+                level=scene["kl"]["octave"], qdesc=scene["dl"], mp_obs=rng.random(n) < 0.9, th=th, nnratio=nnratio)
+    n_gpu, m_gpu = scene["m"].SearchByProjectionPointsResident(res, **args)
+    n_ref, m_ref = scene["OM"].SearchByProjectionPoints(view, **args)
+    assert n_gpu == n_ref and np.array_equal(m_gpu, m_ref)
+    res.close()
+
+
+def test_resident_frame_adopts_extractor_results(pkg, scene, synth):
+    """A resident frame made from device pointers (one frame of an extractor's result block, no copy of keypoints or
+    descriptors) gives the same search result as one uploaded from the host arrays."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    ex = scene["exr"]
+    ex(scene["r"], (0, 0))                                      # the right view's results are the extractor's current block
+    r = ex.result_device()
+    kr, dr = scene["kr"], scene["dr"]
+    res_dev = pkg.ResidentFrame(scene["m"], device=dict(kps=r["kps"], desc=r["desc"], n=len(kr)), width=752, height=480)
+    view = pkg.FrameView(kr, dr, 752, 480, backend=scene["OM"])
+    n, u, v = _queries(scene, rng)
+    args = dict(cur_blocked=rng.random(len(kr)) < 0.05, scale_factors=scene["sf"], valid=rng.random(n) < 0.85, u=u, v=v,
+                invzc=rng.uniform(0.05, 1.0, n), octave=scene["kl"]["octave"], angle=scene["kl"]["angle"], qdesc=scene["dl"],
+                mp_obs=rng.random(n) < 0.9, th=15, forward=False, backward=False, mbf=47.9, check_ori=True)
+    n_gpu, m_gpu = scene["m"].SearchByProjectionFrameResident(res_dev, **args)
+    n_ref, m_ref = scene["OM"].SearchByProjectionFrame(view, **args)
+    assert n_gpu == n_ref and np.array_equal(m_gpu, m_ref) and n_ref > 50
+    res_dev.close()
