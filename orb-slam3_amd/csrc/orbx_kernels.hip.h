@@ -96,6 +96,15 @@ __device__ __forceinline__ uint4 gload128(const void* p) { return *(const uint4*
 __device__ __forceinline__ u8 gload8(const void* p) { return *(const u8*)p; }
 #endif
 
+// XCD-aware work order.  Workgroup ids are dealt round-robin over the 8 XCDs (ids b and b + 8 share an XCD and its L2), so a
+// task list in which NEIGHBOURING tasks touch the same memory lines (adjacent column groups / strips of one image share their
+// halo lines) must be walked so that neighbours get ids that are 8 apart: id b takes the (b / 8)-th task of the (b % 8)-th
+// eighth of the list.  Placement is never relied on for correctness, only for L2 hits.
+__device__ __forceinline__ unsigned xcd_task(unsigned b, unsigned n) {
+    const unsigned q = n >> 3, rem = n & 7u, x = b & 7u;
+    return x * q + (x < rem ? x : rem) + (b >> 3);
+}
+
 __device__ __forceinline__ const u8* level_ptr(const Geom& g, const u8* const* l0, int l0pitch,
                                                const u8* pyr, int frame, int level, int* pitch) {
     if (level == 0) {
@@ -410,6 +419,9 @@ struct StripInfo { short level, ncell, x0, y0, w, h, xal, lp; int cell0; };   //
 // survivors do not fit is handed to k_fast_fix through a global list.
 // ------------------------------------------------------------------------------------------------
 #define F3_NT 256
+#ifndef F3_XCD
+#define F3_XCD 1                                            // neighbouring strips (they share 6 columns and whole lines) on one XCD
+#endif
 __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
                                                  const CellInfo* __restrict__ cells, const StripInfo* __restrict__ strips,
                                                  u32* candCnt, u32* candEnt, int* err, int tileBytes, int qcap,
@@ -417,7 +429,7 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
     extern __shared__ __attribute__((aligned(16))) unsigned char f3smem[];
     u8* img = f3smem;
     u8* sc = f3smem + tileBytes;
-    StripInfo st = strips[gridDim.x - 1 - blockIdx.x];                // coarser (denser, slower) strips of the group first: a lighter tail
+    StripInfo st = strips[gridDim.x - 1 - (F3_XCD ? xcd_task(blockIdx.x, gridDim.x) : blockIdx.x)];   // coarser (denser, slower) strips of the group first: a lighter tail
     st.level = (short)__builtin_amdgcn_readfirstlane(st.level);
     const int frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);              // wave-uniform: per-cell metadata comes through the scalar cache
@@ -1250,6 +1262,9 @@ __device__ __forceinline__ int reflect101(int p, int n) {   // valid for -n < p 
 // geometry is built (built in the kernel they cost more than the tiles themselves); border folds are just table entries.
 // ------------------------------------------------------------------------------------------------
 #define B3_ROWS 26
+#ifndef B3_XCD
+#define B3_XCD 1                                            // adjacent column groups on one XCD: their shared halo lines hit in L2
+#endif
 #ifndef B3_CHUNK
 #define B3_CHUNK 8
 #endif
@@ -1307,7 +1322,7 @@ __global__ __launch_bounds__(256) void k_blur3(Geom g, const u8* const* l0, int 
     __shared__ __attribute__((aligned(16))) u8 ob[2][32 * B3_OROW];   // blurred tile of the workgroup, 32 rows x 128 px
     const int tid = threadIdx.x, lane = tid & 63;
     const int cb = __builtin_amdgcn_readfirstlane(tid >> 6);            // this wave's 32-px column block of the 128-px group
-    Blur3Task t = tasks[blockIdx.x];                                    // one task per workgroup: (level, 128-px group, tile chunk)
+    Blur3Task t = tasks[B3_XCD ? xcd_task(blockIdx.x, gridDim.x) : blockIdx.x];   // one task per workgroup: (level, 128-px group, tile chunk)
     t.level = (short)__builtin_amdgcn_readfirstlane(t.level);
     t.x0 = (short)__builtin_amdgcn_readfirstlane(t.x0);
     t.t0 = (short)__builtin_amdgcn_readfirstlane(t.t0);
