@@ -35,7 +35,21 @@ struct orbm {
     // (a dozen hipMalloc / small pageable copies per call cost over a millisecond).
     uint8_t* arDev = nullptr; uint8_t* arPin = nullptr;
     size_t arCap = 0, arOff = 0, arUp = 0, arOutLo = (size_t)-1, arOutHi = 0;   // bump offset; [0, arUp) staged uploads; small outputs in [arOutLo, arOutHi)
+    uint8_t* scr = nullptr; size_t scrCap = 0;                 // grow-only device scratch of the batched (enqueue-only) entry points
 };
+
+// scratch of the enqueue-only entry points: grows outside a capture only (an allocation cannot be recorded into a graph)
+static uint8_t* batch_scratch(orbm* m, size_t bytes) {
+    if (bytes <= m->scrCap && m->scr) return m->scr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(m->stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) return nullptr;
+    (void)hipStreamSynchronize(m->stream);
+    if (m->scr) (void)hipFree(m->scr);
+    m->scr = nullptr; m->scrCap = 0;
+    if (hipMalloc((void**)&m->scr, bytes) != hipSuccess) return nullptr;
+    m->scrCap = bytes;
+    return m->scr;
+}
 
 // time stamps: under stream capture (the caller replays this enqueue sequence as a HIP graph, orbx_capture_begin) an event
 // record stamps nothing on replay, so it is skipped there: orbm_last_timing keeps reporting the last eagerly enqueued call
@@ -84,6 +98,7 @@ void orbm_destroy(orbm_t* m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->ownStream) { (void)hipStreamSynchronize(m->ownStream); (void)hipStreamDestroy(m->ownStream); }
     if (m->arDev) (void)hipFree(m->arDev);
+    if (m->scr) (void)hipFree(m->scr);
     if (m->arPin) (void)hipHostFree(m->arPin);
     if (m->e0) (void)hipEventDestroy(m->e0);
     if (m->e1) (void)hipEventDestroy(m->e1);
@@ -1529,25 +1544,34 @@ int orbm_stereo_matches(orbm_t* m, void* left, int frame_l, void* right, int fra
 // ---- batched, device-resident forms of M15 / 8(f).1 / M10 (config C3 of bench.py: nothing leaves HBM between the extraction and
 // the match lists) ------------------------------------------------------------------------------------------
 extern "C" int orbx_internal_batch_layout(void* o, const uint8_t* const** l0tab, int* l0pitch, const uint8_t** pyr, size_t* frameBytes,
-                                          int* nlevels, int* off, int* pitch, int* w, float* sf, float* isf, int* device, int* maxBatch, int* kpCap);
+                                          int* nlevels, int* off, int* pitch, int* w, int* h, float* sf, float* isf, int* device, int* maxBatch, int* kpCap);
 
 int orbm_stereo_batch_async(orbm_t* m, void* extractor, int first_l, int first_r, int npairs, const orbm_kp_t* kps, const uint8_t* desc,
                             const int32_t* counts, int cap, float mb, float mbf, float* uright, float* depth, int32_t* sad, int32_t* kept) {
     if (!m || !extractor || !kps || !desc || !counts || !uright || !depth || !sad || !kept || npairs < 1 || first_l < 0 || first_r < 0 || cap < 1 || cap > 65535) return ORBM_E_INVALID;
     StereoBatchLayout B;
     memset(&B, 0, sizeof B);
-    int nlev = 0, dev = 0, maxBatch = 0, kpCap = 0;
-    if (orbx_internal_batch_layout(extractor, &B.l0, &B.l0pitch, &B.pyr, &B.frameBytes, &nlev, B.off, B.pitch, B.w, B.sf, B.isf, &dev, &maxBatch, &kpCap)) {
+    int nlev = 0, dev = 0, maxBatch = 0, kpCap = 0, hl[12] = {};
+    if (orbx_internal_batch_layout(extractor, &B.l0, &B.l0pitch, &B.pyr, &B.frameBytes, &nlev, B.off, B.pitch, B.w, hl, B.sf, B.isf, &dev, &maxBatch, &kpCap)) {
         set_merr("the extractor handle holds no geometry"); return ORBM_E_INVALID;
     }
     if (dev != m->device || cap != kpCap || first_l + npairs > maxBatch || first_r + npairs > maxBatch) { set_merr("extractor / matcher mismatch (device, capacity or batch range)"); return ORBM_E_INVALID; }
     MHIPCHK(hipSetDevice(m->device));
     int n2 = 64; while (n2 < cap) n2 <<= 1;
     if (n2 * 4 > 48 * 1024) MHIPCHK(hipFuncSetAttribute((const void*)k_stereo_cut, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 4));
+    // vRowIndices (Frame.cc:1064-1083) of every right image as CSR in the handle's scratch: [npairs][nrows + 1] starts + [npairs][rowCap] indices
+    const int nrows = hl[0], rowCap = 16 * cap;                  // a band spans <= 2 * ceil(2 * 1.2^11) + 1 rows at 12 levels; 16 per keypoint is never reached at 8
+    const size_t bStart = ((size_t)npairs * (nrows + 1) * sizeof(int) + 255) & ~(size_t)255, bIdx = ((size_t)npairs * rowCap * sizeof(unsigned short) + 255) & ~(size_t)255;
+    uint8_t* scr = batch_scratch(m, bStart + bIdx + 256);
+    if (!scr) { set_merr("stereo scratch of %zu B unavailable (inside a capture, run the call once eagerly first)", bStart + bIdx + 256); return ORBM_E_HIP; }
+    int* rowStart = (int*)scr; unsigned short* rowIdx = (unsigned short*)(scr + bStart); int* rowErr = (int*)(scr + bStart + bIdx);
+    const size_t ldsRows = (size_t)(2 * nrows + 2) * sizeof(int);
+    if (ldsRows > 48 * 1024) MHIPCHK(hipFuncSetAttribute((const void*)k_stereo_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsRows));
     m->gridFirst = false;
     MHIPCHK(rec_time(m, m->e0));
+    hipLaunchKernelGGL(k_stereo_rows, dim3(npairs), dim3(256), ldsRows, m->stream, (const KpIn*)kps, counts, cap, first_r, B, nrows, rowCap, rowStart, rowIdx, rowErr);
     hipLaunchKernelGGL(k_stereo_batch, dim3((cap + 3) / 4, npairs), dim3(256), 0, m->stream, (const KpIn*)kps, desc, counts, cap, first_l, first_r, B, mb, mbf,
-                       uright, depth, sad);
+                       uright, depth, sad, rowStart, rowIdx, nrows, rowCap);
     hipLaunchKernelGGL(k_stereo_cut, dim3(npairs), dim3(256), (size_t)n2 * 4, m->stream, counts, cap, first_l, n2, sad, uright, depth, kept);
     MHIPCHK(rec_time(m, m->e1));
     m->timed = true;
@@ -1577,9 +1601,14 @@ int orbm_triangulation_batch_async(orbm_t* m, int npairs, int cap,
     for (int i = 0; i < 9; ++i) P.F12[i] = F12[i];
     P.epx = epx; P.epy = epy; P.onlyStereo = only_stereo; P.coarse = coarse;
     for (int i = 0; i < 12; ++i) { P.sf2[i] = scale_factors2[std::min(i, nlevels - 1)]; P.sigma2[i] = level_sigma2_2[std::min(i, nlevels - 1)]; }
+    const size_t bS = ((size_t)npairs * 257 * sizeof(int) + 255) & ~(size_t)255, bI = ((size_t)npairs * cap * sizeof(unsigned short) + 255) & ~(size_t)255;
+    uint8_t* scr = batch_scratch(m, bS + bI);
+    if (!scr) { set_merr("triangulation scratch of %zu B unavailable (inside a capture, run the call once eagerly first)", bS + bI); return ORBM_E_HIP; }
+    int* bStart = (int*)scr; unsigned short* bIdx = (unsigned short*)(scr + bS);
     MHIPCHK(hipMemsetAsync(nmatches, 0, sizeof(int) * npairs, m->stream));
+    hipLaunchKernelGGL(k_tri_buckets, dim3(npairs), dim3(256), 0, m->stream, counts2, node2, cap, bStart, bIdx);
     hipLaunchKernelGGL(k_triangulate_batch, dim3((cap + 3) / 4, npairs), dim3(256), 0, m->stream, (const KpIn*)kps1, desc1, counts1, node1, uright1,
-                       (const KpIn*)kps2, desc2, counts2, node2, uright2, cap, P, matches12, nmatches);
+                       (const KpIn*)kps2, desc2, counts2, node2, uright2, cap, P, matches12, nmatches, bStart, bIdx);
     MHIPCHK(hipGetLastError());
     return ORBM_OK;
 }

@@ -497,11 +497,15 @@ __global__ __launch_bounds__(256) void k_pairdist(const uint8_t* __restrict__ d1
 struct StereoLevels { const uint8_t* L[12]; const uint8_t* R[12]; int pitchL[12], pitchR[12], wR[12]; float sf[12], isf[12]; };
 
 // LV supplies the pyramids: sf(o), isf(o), L(level), R(level), pitchL(level), pitchR(level), wR(level)
+// rowStart / rowIdx (optional): the reference's vRowIndices table (Frame.cc:1064-1083) as CSR over image rows -- the right
+// keypoints whose band [floor(y - r), ceil(y + r)] covers a row; with it a left keypoint only looks at the ~20 keypoints of its
+// row instead of all of them.  The winner is min (distance, iR) either way, so the order inside a row list does not matter.
 template <class LV>
 __device__ __forceinline__ void stereo_body(const KpIn* __restrict__ kl, const uint8_t* __restrict__ dl, int nl,
                                             const KpIn* __restrict__ kr, const uint8_t* __restrict__ dr, int nr,
                                             const LV& lv, float mb, float mbf, float* __restrict__ uright,
-                                            float* __restrict__ depth, int* __restrict__ bestSad, int iL) {
+                                            float* __restrict__ depth, int* __restrict__ bestSad, int iL,
+                                            const int* __restrict__ rowStart = nullptr, const unsigned short* __restrict__ rowIdx = nullptr, int nrows = 0) {
     const int lane = threadIdx.x & 63;
     const KpIn kpL = kl[iL];
     const int levelL = kpL.octave;
@@ -517,8 +521,11 @@ __device__ __forceinline__ void stereo_body(const KpIn* __restrict__ kl, const u
         const u64 a[4] = {(u64)qlo.x | ((u64)qlo.y << 32), (u64)qlo.z | ((u64)qlo.w << 32),
                           (u64)qhi.x | ((u64)qhi.y << 32), (u64)qhi.z | ((u64)qhi.w << 32)};
         unsigned int best = 0xFFFFFFFFu;                                     // (dist << 16) | iR, strict < keeps the first
-        for (int b0 = 0; b0 < nr; b0 += 64) {
-            const int iR = b0 + lane;
+        int c0 = 0, c1 = nr;
+        if (rowStart) { if (rowL >= 0 && rowL < nrows) { c0 = rowStart[rowL]; c1 = rowStart[rowL + 1]; } else c1 = 0; }
+        for (int b0 = c0; b0 < c1; b0 += 64) {
+            const int ci = b0 + lane;
+            const int iR = rowStart ? (ci < c1 ? (int)rowIdx[ci] : nr) : ci;
             if (iR < nr) {
                 const KpIn kpR = kr[iR];
                 const float r = 2.0f * lv.sf(kpR.octave);
@@ -631,9 +638,56 @@ struct StereoBatchView {
     __device__ int pitchR(int l) const { return l == 0 ? b.l0pitch : b.pitch[l]; }
     __device__ int wR(int l) const { return b.w[l]; }
 };
+// k_stereo_rows: vRowIndices of every pair's right image as CSR (Frame.cc:1064-1083): rowStart [npairs][nrows + 1],
+// rowIdx [npairs][rowCap] (right keypoint indices; a keypoint enters the rows of its band).  One workgroup per pair: band
+// histogram in LDS -> exclusive scan -> scatter.  Entries beyond rowCap are dropped and flagged (never with rowCap = 16 * cap).
+__global__ __launch_bounds__(256) void k_stereo_rows(const KpIn* __restrict__ kps, const int* __restrict__ counts, int cap, int first_r,
+                                                     StereoBatchLayout B, int nrows, int rowCap, int* __restrict__ rowStart,
+                                                     unsigned short* __restrict__ rowIdx, int* __restrict__ err) {
+    extern __shared__ int srow[];                                        // [nrows + 1] counts -> starts, then fill cursors [nrows]
+    const int pair = blockIdx.x, tid = threadIdx.x, fr = first_r + pair;
+    const int nr = min(counts[fr], cap);
+    const KpIn* kr = kps + (size_t)fr * cap;
+    int* cur = srow + nrows + 1;
+    for (int i = tid; i <= nrows; i += 256) srow[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < nr; i += 256) {
+        const float r = 2.0f * B.sf[kr[i].octave];
+        const int maxr = min((int)ceilf(kr[i].y + r), nrows - 1), minr = max((int)floorf(kr[i].y - r), 0);
+        for (int y = minr; y <= maxr; ++y) atomicAdd(&srow[y], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {                                                      // exclusive scan of the row counts by one wave
+        int carry = 0;
+        for (int b0 = 0; b0 <= nrows; b0 += 64) {
+            const int i = b0 + tid;
+            const int v = i < nrows ? srow[i] : 0;
+            int sc_ = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(sc_, o); if (tid >= o) sc_ += t; }
+            if (i <= nrows) srow[i] = carry + sc_ - v;
+            carry += __shfl(sc_, 63);
+        }
+    }
+    __syncthreads();
+    int* rs = rowStart + (size_t)pair * (nrows + 1);
+    for (int i = tid; i <= nrows; i += 256) { rs[i] = min(srow[i], rowCap); if (i < nrows) cur[i] = srow[i]; }
+    __syncthreads();
+    unsigned short* ri = rowIdx + (size_t)pair * rowCap;
+    for (int i = tid; i < nr; i += 256) {
+        const float r = 2.0f * B.sf[kr[i].octave];
+        const int maxr = min((int)ceilf(kr[i].y + r), nrows - 1), minr = max((int)floorf(kr[i].y - r), 0);
+        for (int y = minr; y <= maxr; ++y) {
+            const int pos = atomicAdd(&cur[y], 1);
+            if (pos < rowCap) ri[pos] = (unsigned short)i; else *err = 1;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_stereo_batch(const KpIn* __restrict__ kps, const uint8_t* __restrict__ desc, const int* __restrict__ counts,
                                                       int cap, int first_l, int first_r, StereoBatchLayout B, float mb, float mbf,
-                                                      float* __restrict__ uright, float* __restrict__ depth, int* __restrict__ bestSad) {
+                                                      float* __restrict__ uright, float* __restrict__ depth, int* __restrict__ bestSad,
+                                                      const int* __restrict__ rowStart, const unsigned short* __restrict__ rowIdx, int nrows, int rowCap) {
     const int pair = blockIdx.y, fl = first_l + pair, fr = first_r + pair;
     const int nl = min(counts[fl], cap), nr = min(counts[fr], cap);
     const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -642,7 +696,8 @@ __global__ __launch_bounds__(256) void k_stereo_batch(const KpIn* __restrict__ k
     const size_t o = (size_t)pair * cap;
     if (nr == 0) { if ((threadIdx.x & 63) == 0) { uright[o + iL] = -1.0f; depth[o + iL] = -1.0f; bestSad[o + iL] = -1; } return; }
     stereo_body(kps + (size_t)fl * cap, desc + (size_t)fl * cap * 32, nl, kps + (size_t)fr * cap, desc + (size_t)fr * cap * 32, nr, v, mb, mbf,
-                uright + o, depth + o, bestSad + o, iL);
+                uright + o, depth + o, bestSad + o, iL, rowStart ? rowStart + (size_t)pair * (nrows + 1) : nullptr,
+                rowIdx ? rowIdx + (size_t)pair * rowCap : nullptr, nrows);
 }
 
 __global__ __launch_bounds__(256) void k_stereo_cut(const int* __restrict__ counts, int cap, int first_l, int n2, const int* __restrict__ bestSad,
@@ -701,13 +756,46 @@ __global__ __launch_bounds__(256) void k_stereo_cut(const int* __restrict__ coun
 // features of KeyFrame 1 are independent.
 // ------------------------------------------------------------------------------------------------
 struct TriParams { float F12[9]; float epx, epy; float sf2[12], sigma2[12]; int onlyStereo, coarse; };
+// k_tri_buckets: the features of every KeyFrame 2 grouped by (vocabulary node & 255): bStart [npairs][257], bIdx [npairs][cap].
+// A FeatureVector bucket is then one short list (plus the few features of other nodes that share the low byte, filtered by
+// the exact node id in the search); the order inside a list does not matter to k_triangulate_batch's min-key reduction.
+__global__ __launch_bounds__(256) void k_tri_buckets(const int* __restrict__ counts2, const int* __restrict__ node2, int cap,
+                                                     int* __restrict__ bStart, unsigned short* __restrict__ bIdx) {
+    __shared__ int hist[257], cur[256];
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int n2 = min(counts2[pair], cap);
+    const int* nd = node2 + (size_t)pair * cap;
+    hist[tid] = 0; if (tid == 0) hist[256] = 0;
+    __syncthreads();
+    for (int i = tid; i < n2; i += 256) atomicAdd(&hist[nd[i] & 255], 1);
+    __syncthreads();
+    if (tid < 64) {
+        int carry = 0;
+        for (int b0 = 0; b0 < 256; b0 += 64) {
+            const int v = hist[b0 + tid];
+            int sc_ = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(sc_, o); if (tid >= o) sc_ += t; }
+            hist[b0 + tid] = carry + sc_ - v;
+            carry += __shfl(sc_, 63);
+        }
+        if (tid == 0) hist[256] = carry;
+    }
+    __syncthreads();
+    bStart[(size_t)pair * 257 + tid] = hist[tid]; if (tid == 0) bStart[(size_t)pair * 257 + 256] = hist[256];
+    cur[tid] = hist[tid];
+    __syncthreads();
+    for (int i = tid; i < n2; i += 256) bIdx[(size_t)pair * cap + atomicAdd(&cur[nd[i] & 255], 1)] = (unsigned short)i;
+}
+
 __global__ __launch_bounds__(256) void k_triangulate_batch(const KpIn* __restrict__ kps1, const uint8_t* __restrict__ desc1, const int* __restrict__ counts1,
                                                            const int* __restrict__ node1, const float* __restrict__ ur1,
                                                            const KpIn* __restrict__ kps2, const uint8_t* __restrict__ desc2, const int* __restrict__ counts2,
                                                            const int* __restrict__ node2, const float* __restrict__ ur2,
-                                                           int cap, TriParams P, int* __restrict__ matches12, int* __restrict__ nmatches) {
+                                                           int cap, TriParams P, int* __restrict__ matches12, int* __restrict__ nmatches,
+                                                           const int* __restrict__ bStart, const unsigned short* __restrict__ bIdx) {
     const int pair = blockIdx.y, lane = threadIdx.x & 63;
-    const int n1 = min(counts1[pair], cap), n2 = min(counts2[pair], cap);
+    const int n1 = min(counts1[pair], cap);
     const int i1 = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i1 >= n1) return;
     const size_t o = (size_t)pair * cap;
@@ -725,9 +813,12 @@ __global__ __launch_bounds__(256) void k_triangulate_batch(const KpIn* __restric
         const float lb = kp1.x * P.F12[1] + kp1.y * P.F12[4] + P.F12[7];
         const float lc = kp1.x * P.F12[2] + kp1.y * P.F12[5] + P.F12[8];
         const float den = la * la + lb * lb;
-        for (int b0 = 0; b0 < n2; b0 += 64) {
-            const int i2 = b0 + lane;
-            if (i2 >= n2 || node2[o + i2] != nd) continue;
+        const int c0 = bStart[(size_t)pair * 257 + (nd & 255)], c1 = bStart[(size_t)pair * 257 + (nd & 255) + 1];
+        for (int b0 = c0; b0 < c1; b0 += 64) {
+            const int ci = b0 + lane;
+            if (ci >= c1) continue;
+            const int i2 = (int)bIdx[o + ci];
+            if (node2[o + i2] != nd) continue;
             const bool bStereo2 = ur2 && ur2[o + i2] >= 0;
             if (P.onlyStereo && !bStereo2) continue;
             const uint4* tp = (const uint4*)(desc2 + (o + i2) * 32);

@@ -55,7 +55,7 @@ struct orbx {
     bool fastV1 = false;
     // k_fast3 launch groups: level 0 (needs no resize), the fine levels, the coarse levels.  Each group sizes its own LDS
     // (tile of its tallest cell row + survivor queues), because occupancy -- 20 vs 28 waves per CU -- is worth ~15 %.
-    struct F3Group { int strip0 = 0, nstrips = 0, tile = 0, qcap = 0, lastLevel = 0; size_t lds = 0; };
+    struct F3Group { int strip0 = 0, nstrips = 0, tile = 0, qcap = 0, lastLevel = 0, pitch = 0; size_t lds = 0; };   // pitch: 176 / 208 = compile-time tile pitch of the group, 0 = per strip
     hipEvent_t evLvl[12] = {};                                // "pyramid level l is resized" for the levels that end a FAST group
     std::vector<F3Group> f3g;
     std::vector<int> stripTile, stripQ;                       // per strip: tile bytes, worst-case queue entries
@@ -133,6 +133,7 @@ struct orbx {
     u32 *dOvf = nullptr, *dOvfList = nullptr;                  // k_fast3 queue overflow list -> k_fast_fix
     size_t capOvfList = 0;
     int f3QcapForce = 0;                                       // ORBX_FAST_QCAP: test knob, forces a small queue
+    bool f3NoFixedPitch = false;                               // ORBX_FAST_PITCH0: A/B, every group on the per-strip-pitch kernel
     int8_t* dPattern = nullptr;
     u32* dOdW = nullptr;                                       // IC_Angle byte weights (k_orient_desc2)
     size_t capL0 = 0, capPyr = 0, capCells = 0, capTiles = 0, capXt = 0, capYt = 0, capCandCnt = 0, capCandEnt = 0, capSel = 0;
@@ -460,8 +461,14 @@ static int build_geometry(orbx* o, int w, int h) {
             orbx::F3Group G;
             G.strip0 = bounds[gi]; G.nstrips = bounds[gi + 1] - bounds[gi];
             if (G.nstrips <= 0) continue;
-            int qworst = 64;
-            for (int si = G.strip0; si < G.strip0 + G.nstrips; ++si) { G.tile = std::max(G.tile, o->stripTile[si]); qworst = std::max(qworst, o->stripQ[si]); }
+            int qworst = 64, maxLp = 0, maxH = 0;
+            for (int si = G.strip0; si < G.strip0 + G.nstrips; ++si) {
+                G.tile = std::max(G.tile, o->stripTile[si]); qworst = std::max(qworst, o->stripQ[si]);
+                maxLp = std::max(maxLp, (int)o->strips[si].lp); maxH = std::max(maxH, (int)o->strips[si].h);
+            }
+            // one compile-time tile pitch for the whole group when its strips allow it (35..40-px cells, 4 per strip: <= 208 bytes)
+            G.pitch = o->f3NoFixedPitch ? 0 : maxLp <= 176 ? 176 : maxLp <= 208 ? 208 : 0;
+            if (G.pitch) G.tile = G.pitch * maxH;
             G.tile = align_up(G.tile, 16);
             G.lastLevel = o->strips[G.strip0 + G.nstrips - 1].level;
             G.qcap = qworst;
@@ -481,7 +488,9 @@ static int build_geometry(orbx* o, int w, int h) {
             maxLds = std::max(maxLds, G.lds);
             o->f3g.push_back(G);
         }
-        HIPCHK(hipFuncSetAttribute((const void*)k_fast3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_fast3<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_fast3<176>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_fast3<208>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
     }
     if (ensure(&o->dOvfList, &o->capOvfList, (size_t)g.totalCells * B)) return ORBX_E_HIP;
     HIPCHK(hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->qtLds));
@@ -591,6 +600,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     o->blurV2 = getenv("ORBX_BLUR_V2") != nullptr;
     o->odV1 = getenv("ORBX_OD_V1") != nullptr;
     if (const char* e = getenv("ORBX_FAST_QCAP")) o->f3QcapForce = atoi(e);
+    o->f3NoFixedPitch = getenv("ORBX_FAST_PITCH0") != nullptr;
     if (const char* e = getenv("ORBX_QT_WIDE")) o->qtWideForce = atoi(e) != 0 ? 1 : 0;
     o->blurEarly = !o->blurV2 && getenv("ORBX_BLUR_LATE") == nullptr;
     o->dlKernel = getenv("ORBX_DL_KERNEL") != nullptr;          // A/B: results-to-host copy by k_copy_out instead of the copy engine
@@ -803,7 +813,8 @@ static int extract_batch_async_impl(orbx_t* o, const uint8_t* const* imgs, int i
                 if (first) STAGE_EV(1, st);
                 first = false;
             }
-            hipLaunchKernelGGL(k_fast3, dim3((unsigned)G.nstrips, nimg), dim3(F3_NT), G.lds, st, g, o->dL0Ptr, l0pitch, o->dPyr,
+            auto kern = G.pitch == 176 ? k_fast3<176> : G.pitch == 208 ? k_fast3<208> : k_fast3<0>;
+            hipLaunchKernelGGL(kern, dim3((unsigned)G.nstrips, nimg), dim3(F3_NT), G.lds, st, g, o->dL0Ptr, l0pitch, o->dPyr,
                                o->dCells, o->dStrips + G.strip0, o->dCandCnt, o->dCandEnt, o->dErr, G.tile, G.qcap, o->dOvf, o->dOvfList);
         }
         if (first) {                                             // single-level extractor
@@ -1402,11 +1413,11 @@ int orbx_internal_levels(orbx_t* o, int frame, int* nlevels, const uint8_t** ptr
 // internal (not part of include/orbx.h): where the batch's pyramids live, for the batched stereo matcher in the same library
 // (orbm_stereo_batch_async).  No sync: the caller orders its kernels behind the extraction on a stream.
 int orbx_internal_batch_layout(orbx_t* o, const uint8_t* const** l0tab, int* l0pitch, const uint8_t** pyr, size_t* frameBytes,
-                               int* nlevels, int* off, int* pitch, int* w, float* sf, float* isf, int* device, int* maxBatch, int* kpCap) {
+                               int* nlevels, int* off, int* pitch, int* w, int* h, float* sf, float* isf, int* device, int* maxBatch, int* kpCap) {
     if (!o || !o->curW) return ORBX_E_INVALID;
     *l0tab = o->dL0Ptr; *l0pitch = o->lastL0Pitch ? o->lastL0Pitch : o->l0pitch; *pyr = o->dPyr; *frameBytes = o->g.pyrFrameBytes;
     *nlevels = o->nlevels; *device = o->device; *maxBatch = o->maxBatch; *kpCap = o->g.kpCap;
-    for (int l = 0; l < o->nlevels; ++l) { const LevelDesc& D = o->g.lv[l]; off[l] = D.off; pitch[l] = D.pitch; w[l] = D.w; sf[l] = o->sf[l]; isf[l] = o->invsf[l]; }
+    for (int l = 0; l < o->nlevels; ++l) { const LevelDesc& D = o->g.lv[l]; off[l] = D.off; pitch[l] = D.pitch; w[l] = D.w; h[l] = D.h; sf[l] = o->sf[l]; isf[l] = o->invsf[l]; }
     return ORBX_OK;
 }
 

@@ -422,6 +422,9 @@ struct StripInfo { short level, ncell, x0, y0, w, h, xal, lp; int cell0; };   //
 #ifndef F3_XCD
 #define F3_XCD 1                                            // neighbouring strips (they share 6 columns and whole lines) on one XCD
 #endif
+// PITCH > 0: every strip of the launch uses this LDS tile pitch (bytes), so that row offsets become instruction immediates
+// (18 address adds per scored pixel pair, and the +-3-row reads of the quick test); PITCH == 0: per-strip pitch st.lp (wide cells).
+template <int PITCH>
 __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
                                                  const CellInfo* __restrict__ cells, const StripInfo* __restrict__ strips,
                                                  u32* candCnt, u32* candEnt, int* err, int tileBytes, int qcap,
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
     const int frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);              // wave-uniform: per-cell metadata comes through the scalar cache
     u16* q = (u16*)(f3smem + 2 * tileBytes) + wv * qcap;
-    const int Pb = st.lp, H = st.h;                                       // lp holds the tile pitch in bytes here
+    const int Pb = PITCH > 0 ? PITCH : (int)st.lp, H = st.h;              // tile pitch in bytes
     // this wave's first cell: fetched now so that its latency hides behind the tile load
     CellInfo cell0 = cells[st.cell0 + min(wv, st.ncell - 1)];
     int sp;
