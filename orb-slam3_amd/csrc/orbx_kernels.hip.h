@@ -2,13 +2,16 @@
 //
 // Pipeline per batch (all kernels are launched over (work-item, frame) so a batch fills the chip):
 //   k_resize2     x(L-1)  level l-1 -> level l, OpenCV INTER_LINEAR fixed point  (ORBextractor.cc:1664-1717)   [k_resize: general fallback]
-//   k_fast3       x3      per 35-px cell: FAST-9/16 score, 3x3 NMS, ini/min threshold   (:1038-1143)          [+ k_fast_fix; k_fast: A/B]
+//   k_fast3<P>    x3      per 35-px cell: FAST-9/16 score, 3x3 NMS, ini/min threshold   (:1038-1143)          [+ k_fast_fix; k_fast: A/B]
 //   k_quadtree2   x1      DistributeOctTree per (frame, level)                            (:688-1034)          [k_quadtree: A/B]
 //   k_slots       x1      octave/size fix-up, level-0 scaling, lapping partition          (:1161-1176,1633-1655)
-//   k_blur2       x1      7x7 Gaussian, sigma 2, reflect-101, bit-exact fixed point       (:1606-1614)
+//   k_blur3       x1      7x7 Gaussian, sigma 2, reflect-101, bit-exact fixed point, as two int8 Toeplitz products on the
+//                         matrix cores (v_mfma_i32_32x32x32_i8)                          (:1606-1614)         [k_blur2: VALU A/B]
 //   k_orient_desc2 x1     IC_Angle + 256-bit steered BRIEF, four keypoints per wavefront  (:91-203)            [k_orient_desc: A/B]
 // Ingest: k_gray (cvtColor), k_remap (stereo rectification), k_clahe_lut / k_clahe_apply.
-// Integer / byte work throughout: no MFMA (HBM-bound stencils, ALU/LDS-bound descriptors).
+// Plumbing: k_stamp (span boundaries of a graph replay), k_copy_out (results to pinned host memory, A/B path).
+// Integer / byte work throughout (the pass is priced against HBM, the kernels are integer-issue bound); the
+// matrix cores only where the work is an exact int8 product (the blur here, the dense Hamming 2-NN in orbm_kernels.hip.h).
 // Compiled with -ffp-contract=off so the few float expressions evaluate exactly as the reference writes them.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -16,7 +16,7 @@ def per_kernel(d, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
-            acc[r["Kernel_Name"].split("(")[0].split("::")[-1]].append(float(r["Counter_Value"]))
+            acc[r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]].append(float(r["Counter_Value"]))
     return f, acc
 
 
