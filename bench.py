@@ -176,7 +176,7 @@ class OrbWorkload:
             self.dev.upload(padded, offset=i * stride * H)
         self.ptrs = (C.c_void_p * B)(*[int(self.dev.ptr + i * stride * H) for i in range(B)])
         self.laps = np.tile(np.array(lap, np.int32), B)
-        self.nblk = 4
+        self.nblk = 8
         self.res = []                                           # device pointers of the result blocks (walked round-robin step by step)
         for blk in range(self.nblk):
             L.orbx_set_result_block(ex.h, blk)
@@ -195,7 +195,7 @@ class OrbWorkload:
         self.h_blk = [pkg.PinnedBuffer(self.host_bytes) for _ in range(self.nblk)]
         self.download = True
         self.graph = args.launch == "graph" and args.match == "knn2"
-        self.nslots = 4
+        self.nslots = 8
         self.captured = False
         self.k = 0
         # the matcher's kernels run on the extractor's stream (batch i's match, then batch i+1's extraction, in order): they are
@@ -314,8 +314,8 @@ class OrbWorkload:
             self.sync()
 
     def step(self):
-        """Batch k goes into result block k % 4; its results leave for the host (copy thread + copy stream) beside batch k+1,
-        which writes the next block; batch k+4 waits for that copy before it rewrites the block."""
+        """Batch k goes into result block k % 8; its results leave for the host (copy thread + copy stream) beside batch k+1,
+        which writes the next block; batch k+8 waits for that copy before it rewrites the block."""
         blk = self.k % self.nblk
         if self.graph:
             rc = self.L.orbx_graph_launch(self.ex.h, self.k % self.nslots)

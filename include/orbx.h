@@ -126,7 +126,7 @@ int orbx_capture_begin(orbx_t*, int slot);
 int orbx_capture_end(orbx_t*);
 int orbx_graph_launch(orbx_t*, int slot);
 /* results -> host (the reference's consumers read mvKeys / mDescriptors on the host, src/Frame.cc:357-366).  The handle owns
- * a ring of FOUR result blocks; a batch writes the current one (orbx_set_result_block(o, 0..3), default 0; orbx_result_device /
+ * a ring of EIGHT result blocks; a batch writes the current one (orbx_set_result_block(o, 0..7), default 0; orbx_result_device /
  * orbx_result_fetch* refer to it).  A block is one allocation holding kps [max_batch][cap], desc [max_batch][cap][32],
  * counts [max_batch] and monos [max_batch] at the byte offsets orbx_result_block_layout reports (they change with the image
  * size).  orbx_result_download_async hands the current block to the handle's copy thread: it waits for the batch that fills

@@ -89,7 +89,7 @@ struct orbx {
     // the batches; a copy kernel has no such stalls but its PCIe writes slow the bandwidth-bound kernels beside it by 5-20 %.
     // Flow control is host-side: a block is `busy` from orbx_result_download_async until its copy has landed, and whoever is
     // about to rewrite a busy block (orbx_extract_batch_async / orbx_graph_launch) waits for it first.
-    static const int kBlocks = 4;
+    static const int kBlocks = 8;                              // 7 batches of slack: a copy call that stalls for several milliseconds never idles the GPU
     hipStream_t stream3 = nullptr;
     hipEvent_t evBatchDone[kBlocks] = {};
     std::thread dlThread; std::mutex dlMu; std::condition_variable dlCv;
@@ -680,7 +680,7 @@ void orbx_destroy(orbx_t* o) {
     for (auto& e : o->evBatchDone) if (e) (void)hipEventDestroy(e);
     if (o->stream3) (void)hipStreamDestroy(o->stream3);
     void* ptrs[] = {o->dPyr, o->dBlur, o->dL0, (void*)o->dL0Ptr, o->dCells, o->dTiles, o->dTiles3, o->dB3Th, o->dB3Tv, o->dStrips, o->dX4, o->dRzTasks, o->dXt, o->dYt, o->dCandCnt, o->dCandEnt,
-                    o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->rb[0].base, o->rb[1].base, o->rb[2].base, o->rb[3].base, o->dWork, o->dLap, o->dErr, o->dPattern, o->dOvf, o->dOvfList, o->dOdW, (void*)o->dStamps};
+                    o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->rb[0].base, o->rb[1].base, o->rb[2].base, o->rb[3].base, o->rb[4].base, o->rb[5].base, o->rb[6].base, o->rb[7].base, o->dWork, o->dLap, o->dErr, o->dPattern, o->dOvf, o->dOvfList, o->dOdW, (void*)o->dStamps};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& set : o->evr) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     if (o->evDone) (void)hipEventDestroy(o->evDone);

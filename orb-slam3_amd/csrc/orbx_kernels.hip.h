@@ -422,6 +422,9 @@ struct StripInfo { short level, ncell, x0, y0, w, h, xal, lp; int cell0; };   //
 // survivors do not fit is handed to k_fast_fix through a global list.
 // ------------------------------------------------------------------------------------------------
 #define F3_NT 256
+#ifndef F3_ASM_SCAN
+#define F3_ASM_SCAN 1
+#endif
 #ifndef F3_XCD
 #define F3_XCD 1                                            // neighbouring strips (they share 6 columns and whole lines) on one XCD
 #endif
@@ -559,7 +562,8 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
                         for (int gq = 0; gq < 4; ++gq) {
                             const us2 X = pkmax(pkmin(uu[gq], dd[gq]), pkmin(ll[gq], rr4[gq]));
                             const us2 Y = pkmin(pkmax(uu[gq], dd[gq]), pkmax(ll[gq], rr4[gq]));
-                            sg[gq] = as_u32((X - (vv[gq] - t2)) | ((vv[gq] + t2) - Y));   // sign bit of a half = survivor
+                            // survivor <=> v - X > t or Y - v > t <=> t - max(v - X, Y - v) < 0 (signed halves, |.| <= 255): sign bit of a half
+                            sg[gq] = as_u32(__builtin_bit_cast(us2, __builtin_bit_cast(ss2, t2) - __builtin_elementwise_max(__builtin_bit_cast(ss2, vv[gq] - X), __builtin_bit_cast(ss2, Y - vv[gq]))));
                         }
                         const u32 Me = __builtin_amdgcn_perm(sg[2], sg[0], 0x07050301u);   // high bytes of px 0,2,4,6
                         const u32 Mo = __builtin_amdgcn_perm(sg[3], sg[1], 0x07050301u);   // px 1,3,5,7
@@ -570,7 +574,26 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
 #endif
                     // wave-inclusive prefix of popcount(m) (0..8) by a DPP scan, then each lane appends its own survivors
                     const int c = __popc(m);
-                    int sc_ = c;
+                    int sc_;
+#if F3_ASM_SCAN
+                    // seven fused DPP adds (the builtin form compiles to a v_mov_dpp + v_mov 0 + v_add per step: 17 VALU); the s_nops
+                    // are the two wait states a DPP read needs behind the VALU write of the same register
+                    asm volatile("s_nop 1\n\t"
+                                 "v_add_u32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                                 "v_add_u32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                                 "v_add_u32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                                 "s_nop 1\n\t"
+                                 "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+                                 "s_nop 1\n\t"
+                                 "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+                                 "s_nop 1\n\t"
+                                 "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                                 "s_nop 1\n\t"
+                                 "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                                 "s_nop 0"
+                                 : "=&v"(sc_) : "v"(c));
+#else
+                    sc_ = c;
                     sc_ += __builtin_amdgcn_update_dpp(0, c, 0x111, 0xf, 0xf, true);        // row_shr:1
                     sc_ += __builtin_amdgcn_update_dpp(0, c, 0x112, 0xf, 0xf, true);        // row_shr:2
                     sc_ += __builtin_amdgcn_update_dpp(0, c, 0x113, 0xf, 0xf, true);        // row_shr:3
@@ -578,6 +601,7 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
                     sc_ += __builtin_amdgcn_update_dpp(0, sc_, 0x118, 0xf, 0xc, true);      // row_shr:8
                     sc_ += __builtin_amdgcn_update_dpp(0, sc_, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1,3
                     sc_ += __builtin_amdgcn_update_dpp(0, sc_, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2,3
+#endif
                     const int tot = __builtin_amdgcn_readlane(sc_, 63);
                     if (n1 + tot > qcap) { ovfl = true; break; }             // wave-uniform; the cell goes to k_fast_fix
                     int pos = n1 + sc_ - c;
