@@ -69,6 +69,8 @@ struct orbm_dframe {
     float min_x = 0, min_y = 0, inv_w = 0, inv_h = 0;
 };
 
+static inline size_t grid_cs_lds(int n) { return (size_t)(2 * GRID_CELLS + 1) * sizeof(int) + (size_t)std::max(n, 1) * sizeof(unsigned short) + 16; }
+
 namespace { int knn2_host(orbm* m, const uint8_t* q, int q_stride, const int32_t* nq, const uint8_t* t, int t_stride, const int32_t* nt,
                           int npairs, int32_t* idx2, int32_t* dist2); }
 
@@ -427,10 +429,15 @@ int orbm_grid_build(orbm_t* m, const orbm_kp_t* kps, int n, float min_x, float m
     arena_reset(m);
     UP(dk, kps, sizeof(KpIn) * n);
     AL(dgs, sizeof(int) * (ORBM_GRID_COLS * ORBM_GRID_ROWS + 1)); AL(dgi, sizeof(int) * (n + 1)); AL(dpl, sizeof(int));
-    MHIPCHK(hipFuncSetAttribute((const void*)k_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 4));
     ARENA_FLUSH(m);
-    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), (size_t)n2 * 4, m->stream, dk.as<KpIn>(), n, n2, min_x, min_y, inv_w, inv_h,
-                       dgs.as<int>(), dgi.as<int>(), dpl.as<int>());
+    if (n <= GRID_CS_MAX)
+        hipLaunchKernelGGL(k_grid_build_cs, dim3(1), dim3(256), grid_cs_lds(n), m->stream, dk.as<KpIn>(), n, min_x, min_y, inv_w, inv_h,
+                           dgs.as<int>(), dgi.as<int>(), dpl.as<int>());
+    else {
+        MHIPCHK(hipFuncSetAttribute((const void*)k_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 4));
+        hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), (size_t)n2 * 4, m->stream, dk.as<KpIn>(), n, n2, min_x, min_y, inv_w, inv_h,
+                           dgs.as<int>(), dgi.as<int>(), dpl.as<int>());
+    }
     MHIPCHK(hipGetLastError());
     MHIPCHK(hipStreamSynchronize(m->stream));
     ARENA_FETCH(m);
@@ -669,11 +676,13 @@ int orbm_frame_create(orbm_t* m, int space, int n, const orbm_kp_t* kps, const u
     f->dGs = (int*)p; p += bGs; f->dGi = (int*)p;
     int* dPlaced = f->dGi + (n + 1);
     if (e == hipSuccess && n > 0) {
-        if (n2 * 4 > 48 * 1024) e = hipFuncSetAttribute((const void*)k_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 4);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), (size_t)n2 * 4, m->stream, f->dKps, n, n2, min_x, min_y, inv_w, inv_h, f->dGs, f->dGi, dPlaced);
-            e = hipGetLastError();
+        if (n <= GRID_CS_MAX)
+            hipLaunchKernelGGL(k_grid_build_cs, dim3(1), dim3(256), grid_cs_lds(n), m->stream, f->dKps, n, min_x, min_y, inv_w, inv_h, f->dGs, f->dGi, dPlaced);
+        else {
+            if (n2 * 4 > 48 * 1024) e = hipFuncSetAttribute((const void*)k_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 4);
+            if (e == hipSuccess) hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), (size_t)n2 * 4, m->stream, f->dKps, n, n2, min_x, min_y, inv_w, inv_h, f->dGs, f->dGi, dPlaced);
         }
+        if (e == hipSuccess) e = hipGetLastError();
     } else if (e == hipSuccess) e = hipMemsetAsync(f->dGs, 0, sizeof(int) * ncells, m->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
     if (e != hipSuccess) { set_merr("resident frame setup failed: %s", hipGetErrorString(e)); orbm_frame_destroy(f); return ORBM_E_HIP; }
@@ -1042,11 +1051,15 @@ int orbm_grid_build_batch_async(orbm_t* m, const orbm_kp_t* kps, const int32_t* 
     MHIPCHK(hipSetDevice(m->device));
     int n2 = 64; while (n2 < cap) n2 <<= 1;
     if ((size_t)n2 * 4 > 150 * 1024) { set_merr("too many keypoints per frame for the LDS sort"); return ORBM_E_CAPACITY; }
-    if (n2 * 4 > 48 * 1024) MHIPCHK(hipFuncSetAttribute((const void*)k_grid_build_batch, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 4));
+    if (cap > GRID_CS_MAX && n2 * 4 > 48 * 1024) MHIPCHK(hipFuncSetAttribute((const void*)k_grid_build_batch, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 4));
     MHIPCHK(rec_time(m, m->e2));
     m->gridFirst = true;                                                    // orbm_last_timing then spans grid build + the next kernel
-    hipLaunchKernelGGL(k_grid_build_batch, dim3(nframes), dim3(256), (size_t)n2 * 4, m->stream, (const KpIn*)kps, counts, cap, n2,
-                       min_x, min_y, inv_w, inv_h, grid_start, grid_idx);
+    if (cap <= GRID_CS_MAX)
+        hipLaunchKernelGGL(k_grid_build_batch_cs, dim3(nframes), dim3(256), grid_cs_lds(cap), m->stream, (const KpIn*)kps, counts, cap,
+                           min_x, min_y, inv_w, inv_h, grid_start, grid_idx);
+    else
+        hipLaunchKernelGGL(k_grid_build_batch, dim3(nframes), dim3(256), (size_t)n2 * 4, m->stream, (const KpIn*)kps, counts, cap, n2,
+                           min_x, min_y, inv_w, inv_h, grid_start, grid_idx);
     MHIPCHK(hipGetLastError());
     return ORBM_OK;
 }
@@ -1572,7 +1585,7 @@ int orbm_stereo_batch_async(orbm_t* m, void* extractor, int first_l, int first_r
     hipLaunchKernelGGL(k_stereo_rows, dim3(npairs), dim3(256), ldsRows, m->stream, (const KpIn*)kps, counts, cap, first_r, B, nrows, rowCap, rowStart, rowIdx, rowErr);
     hipLaunchKernelGGL(k_stereo_batch, dim3((cap + 3) / 4, npairs), dim3(256), 0, m->stream, (const KpIn*)kps, desc, counts, cap, first_l, first_r, B, mb, mbf,
                        uright, depth, sad, rowStart, rowIdx, nrows, rowCap);
-    hipLaunchKernelGGL(k_stereo_cut, dim3(npairs), dim3(256), (size_t)n2 * 4, m->stream, counts, cap, first_l, n2, sad, uright, depth, kept);
+    hipLaunchKernelGGL(k_stereo_cut, dim3(npairs), dim3(256), 0, m->stream, counts, cap, first_l, n2, sad, uright, depth, kept);
     MHIPCHK(rec_time(m, m->e1));
     m->timed = true;
     MHIPCHK(hipGetLastError());
@@ -1607,7 +1620,7 @@ int orbm_triangulation_batch_async(orbm_t* m, int npairs, int cap,
     int* bStart = (int*)scr; unsigned short* bIdx = (unsigned short*)(scr + bS);
     MHIPCHK(hipMemsetAsync(nmatches, 0, sizeof(int) * npairs, m->stream));
     hipLaunchKernelGGL(k_tri_buckets, dim3(npairs), dim3(256), 0, m->stream, counts2, node2, cap, bStart, bIdx);
-    hipLaunchKernelGGL(k_triangulate_batch, dim3((cap + 3) / 4, npairs), dim3(256), 0, m->stream, (const KpIn*)kps1, desc1, counts1, node1, uright1,
+    hipLaunchKernelGGL(k_triangulate_batch, dim3((cap + 255) / 256, npairs), dim3(256), 0, m->stream, (const KpIn*)kps1, desc1, counts1, node1, uright1,
                        (const KpIn*)kps2, desc2, counts2, node2, uright2, cap, P, matches12, nmatches, bStart, bIdx);
     MHIPCHK(hipGetLastError());
     return ORBM_OK;

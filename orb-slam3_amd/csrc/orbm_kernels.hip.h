@@ -251,6 +251,78 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t* __restrict__ q
 // ------------------------------------------------------------------------------------------------
 struct KpIn { float x, y, size, angle, response; int octave, class_id; };
 
+// Counting sort form of the grid build (n <= GRID_CS_MAX): cell histogram in LDS -> exclusive scan over the 3072 cells ->
+// scatter into a per-cell cursor -> each cell's short list sorted by keypoint index (insertion order of the reference,
+// Frame.cc:446-480: i ascending) -> written out.  One pass over the keypoints instead of a 66-stage bitonic sort of n keys.
+#define GRID_CS_MAX 8192
+#define GRID_CELLS (64 * 48)
+__device__ __forceinline__ int grid_build_counting(const KpIn* __restrict__ kp, int n, float min_x, float min_y, float inv_w, float inv_h,
+                                                   int* __restrict__ gs, int* __restrict__ gi, unsigned char* smem) {
+    int* hist = (int*)smem;                                    // [GRID_CELLS + 1] counts -> starts
+    int* cur = hist + GRID_CELLS + 1;                          // [GRID_CELLS] fill cursors
+    unsigned short* lgi = (unsigned short*)(cur + GRID_CELLS); // [n] indices, cell by cell
+    __shared__ int s_wave[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int c = tid; c <= GRID_CELLS; c += 256) hist[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int px = (int)roundf((kp[i].x - min_x) * inv_w);              // PosInGrid: round, not floor (Frame.cc:888-889)
+        const int py = (int)roundf((kp[i].y - min_y) * inv_h);
+        if (px >= 0 && px < 64 && py >= 0 && py < 48) atomicAdd(&hist[px * 48 + py], 1);
+    }
+    __syncthreads();
+    // exclusive scan: thread t owns cells [12 t, 12 t + 12) (3072 = 256 * 12)
+    int loc[12], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { loc[k] = hist[12 * tid + k]; sum += loc[k]; }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    int base = inc - sum;
+    for (int w = 0; w < wv; ++w) base += s_wave[w];
+    const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { hist[12 * tid + k] = base; cur[12 * tid + k] = base; base += loc[k]; }
+    if (tid == 0) hist[GRID_CELLS] = total;
+    __syncthreads();
+    for (int c = tid; c <= GRID_CELLS; c += 256) gs[c] = hist[c];
+    for (int i = tid; i < n; i += 256) {
+        const int px = (int)roundf((kp[i].x - min_x) * inv_w);
+        const int py = (int)roundf((kp[i].y - min_y) * inv_h);
+        if (px >= 0 && px < 64 && py >= 0 && py < 48) lgi[atomicAdd(&cur[px * 48 + py], 1)] = (unsigned short)i;
+    }
+    __syncthreads();
+    for (int c = tid; c < GRID_CELLS; c += 256) {                            // restore insertion order inside every cell (lists are short)
+        const int a = hist[c], b = hist[c + 1];
+        for (int i = a + 1; i < b; ++i) {
+            const unsigned short v = lgi[i];
+            int j = i - 1;
+            while (j >= a && lgi[j] > v) { lgi[j + 1] = lgi[j]; --j; }
+            lgi[j + 1] = v;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < total; i += 256) gi[i] = (int)lgi[i];
+    return total;
+}
+__global__ __launch_bounds__(256) void k_grid_build_cs(const KpIn* __restrict__ kps, int n, float min_x, float min_y, float inv_w, float inv_h,
+                                                       int* __restrict__ grid_start, int* __restrict__ grid_idx, int* __restrict__ placed) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    const int total = grid_build_counting(kps, n, min_x, min_y, inv_w, inv_h, grid_start, grid_idx, gsm);
+    if (threadIdx.x == 0) *placed = total;
+}
+__global__ __launch_bounds__(256) void k_grid_build_batch_cs(const KpIn* __restrict__ kps, const int* __restrict__ counts, int cap,
+                                                             float min_x, float min_y, float inv_w, float inv_h,
+                                                             int* __restrict__ grid_start, int* __restrict__ grid_idx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    const int frame = blockIdx.x;
+    (void)grid_build_counting(kps + (size_t)frame * cap, min(counts[frame], cap), min_x, min_y, inv_w, inv_h,
+                              grid_start + (size_t)frame * (GRID_CELLS + 1), grid_idx + (size_t)frame * cap, gsm);
+}
+
 __global__ __launch_bounds__(256) void k_grid_build(const KpIn* __restrict__ kps, int n, int n2, float min_x, float min_y,
                                                     float inv_w, float inv_h, int* __restrict__ grid_start,
                                                     int* __restrict__ grid_idx, int* __restrict__ placed) {
@@ -700,50 +772,68 @@ __global__ __launch_bounds__(256) void k_stereo_batch(const KpIn* __restrict__ k
                 rowIdx ? rowIdx + (size_t)pair * rowCap : nullptr, nrows);
 }
 
+// the element of rank m/2 of the pair's SAD values (< 2^15: 121 pixels x 255) by a two-level histogram -- 256 bins of sad >> 7,
+// then 128 bins of the low 7 bits inside the bin that holds the rank -- instead of sorting them
 __global__ __launch_bounds__(256) void k_stereo_cut(const int* __restrict__ counts, int cap, int first_l, int n2, const int* __restrict__ bestSad,
                                                     float* __restrict__ uright, float* __restrict__ depth, int* __restrict__ kept) {
-    extern __shared__ unsigned int cutKeys[];
-    __shared__ int s_m;
+    __shared__ int hist[256];
+    __shared__ int s_m, s_bin, s_before, s_med, s_kept;
+    (void)n2;
     const int pair = blockIdx.x, tid = threadIdx.x;
     const int nl = min(counts[first_l + pair], cap);
     const size_t o = (size_t)pair * cap;
-    if (tid == 0) s_m = 0;
-    __syncthreads();
-    for (int i = tid; i < n2; i += 256) {
-        unsigned int key = 0xFFFFFFFFu;
-        if (i < nl) { const int sdv = bestSad[o + i]; if (sdv >= 0) { key = (unsigned)sdv; atomicAdd(&s_m, 1); } }
-        cutKeys[i] = key;
-    }
-    __syncthreads();
-    for (int k = 2; k <= n2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n2; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned a = cutKeys[i], b = cutKeys[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { cutKeys[i] = b; cutKeys[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    const int m = s_m;
-    if (m == 0) { if (tid == 0) kept[pair] = 0; return; }
-    const float median = (float)cutKeys[m / 2];
-    const float thDist = 1.5f * 1.4f * median;
-    __syncthreads();
-    if (tid == 0) s_m = 0;
+    hist[tid] = 0;
+    if (tid == 0) { s_m = 0; s_kept = 0; }
     __syncthreads();
     int mine = 0;
+    for (int i = tid; i < nl; i += 256) { const int v = bestSad[o + i]; if (v >= 0) { atomicAdd(&hist[min(v >> 7, 255)], 1); ++mine; } }
+    atomicAdd(&s_m, mine);
+    __syncthreads();
+    const int m = s_m;
+    if (m == 0) { if (tid == 0) kept[pair] = 0; return; }
+    const int rank = m / 2;                                                  // vDistIdx[size / 2] of the sorted list (Frame.cc:1263)
+    auto locate = [&](int r, int nb) {                                       // bin whose cumulative count first exceeds r; s_before = count below it
+        if (tid < 64) {
+            int carry = 0;
+            for (int b0 = 0; b0 < nb; b0 += 64) {
+                const int v = hist[b0 + tid];
+                int inc = v;
+#pragma unroll
+                for (int s_ = 1; s_ < 64; s_ <<= 1) { const int t = __shfl_up(inc, s_); if (tid >= s_) inc += t; }
+                const unsigned long long hit = __ballot(carry + inc > r);
+                if (hit) {
+                    const int l = __builtin_ctzll(hit);
+                    if (tid == l) { s_bin = b0 + l; s_before = carry + inc - v; }
+                    break;
+                }
+                carry += __shfl(inc, 63);
+            }
+        }
+    };
+    locate(rank, 256);
+    __syncthreads();
+    const int hb = s_bin, before = s_before;
+    __syncthreads();
+    if (tid < 128) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < nl; i += 256) { const int v = bestSad[o + i]; if (v >= 0 && min(v >> 7, 255) == hb) atomicAdd(&hist[hb == 255 ? min(v - (255 << 7), 127) : (v & 127)], 1); }
+    __syncthreads();
+    locate(rank - before, 128);
+    __syncthreads();
+    if (tid == 0) s_med = (hb << 7) + s_bin;
+    __syncthreads();
+    const float median = (float)s_med;
+    const float thDist = 1.5f * 1.4f * median;
+    mine = 0;
     for (int i = tid; i < nl; i += 256) {
         const int sdv = bestSad[o + i];
         if (sdv < 0) continue;
         if ((float)sdv < thDist) ++mine;
         else { uright[o + i] = -1.0f; depth[o + i] = -1.0f; }
     }
-    atomicAdd(&s_m, mine);
+    atomicAdd(&s_kept, mine);
     __syncthreads();
-    if (tid == 0) kept[pair] = s_m;
+    if (tid == 0) kept[pair] = s_kept;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -794,59 +884,58 @@ __global__ __launch_bounds__(256) void k_triangulate_batch(const KpIn* __restric
                                                            const int* __restrict__ node2, const float* __restrict__ ur2,
                                                            int cap, TriParams P, int* __restrict__ matches12, int* __restrict__ nmatches,
                                                            const int* __restrict__ bStart, const unsigned short* __restrict__ bIdx) {
-    const int pair = blockIdx.y, lane = threadIdx.x & 63;
+    // one THREAD per feature of KeyFrame 1 (a bucket holds a dozen candidates: a wave per feature spent its time on the chain of
+    // dependent loads, not on the distances); the bucket is walked serially, the survivor is the min of (dist << 16 | 0xFFFF - idx2)
+    const int pair = blockIdx.y;
     const int n1 = min(counts1[pair], cap);
-    const int i1 = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i1 >= n1) return;
+    const int i1 = blockIdx.x * 256 + threadIdx.x;
     const size_t o = (size_t)pair * cap;
-    const KpIn kp1 = kps1[o + i1];
-    const int nd = node1[o + i1];
-    const bool bStereo1 = ur1 && ur1[o + i1] >= 0;
-    unsigned int best = 0xFFFFFFFFu;
-    if (!(P.onlyStereo && !bStereo1)) {
-        const uint4* qp = (const uint4*)(desc1 + (o + i1) * 32);
-        const uint4 qlo = qp[0], qhi = qp[1];
-        const u64 a[4] = {(u64)qlo.x | ((u64)qlo.y << 32), (u64)qlo.z | ((u64)qlo.w << 32),
-                          (u64)qhi.x | ((u64)qhi.y << 32), (u64)qhi.z | ((u64)qhi.w << 32)};
-        // the epipolar line of kp1 in image 2 (Pinhole::epipolarConstrain_, Pinhole.cpp:281-287)
-        const float la = kp1.x * P.F12[0] + kp1.y * P.F12[3] + P.F12[6];
-        const float lb = kp1.x * P.F12[1] + kp1.y * P.F12[4] + P.F12[7];
-        const float lc = kp1.x * P.F12[2] + kp1.y * P.F12[5] + P.F12[8];
-        const float den = la * la + lb * lb;
-        const int c0 = bStart[(size_t)pair * 257 + (nd & 255)], c1 = bStart[(size_t)pair * 257 + (nd & 255) + 1];
-        for (int b0 = c0; b0 < c1; b0 += 64) {
-            const int ci = b0 + lane;
-            if (ci >= c1) continue;
-            const int i2 = (int)bIdx[o + ci];
-            if (node2[o + i2] != nd) continue;
-            const bool bStereo2 = ur2 && ur2[o + i2] >= 0;
-            if (P.onlyStereo && !bStereo2) continue;
-            const uint4* tp = (const uint4*)(desc2 + (o + i2) * 32);
-            const uint4 lo = tp[0], hi = tp[1];
-            const int d = ham256(a, (u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
-                                 (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32));
-            if (d > 50) continue;                                                // TH_LOW
-            const KpIn kp2 = kps2[o + i2];
-            if (!bStereo1 && !bStereo2) {
-                const float distex = P.epx - kp2.x, distey = P.epy - kp2.y;
-                if (distex * distex + distey * distey < 100 * P.sf2[kp2.octave]) continue;
+    int res = -1;
+    if (i1 < n1) {
+        const KpIn kp1 = kps1[o + i1];
+        const int nd = node1[o + i1];
+        const bool bStereo1 = ur1 && ur1[o + i1] >= 0;
+        unsigned int best = 0xFFFFFFFFu;
+        if (!(P.onlyStereo && !bStereo1)) {
+            const uint4* qp = (const uint4*)(desc1 + (o + i1) * 32);
+            const uint4 qlo = qp[0], qhi = qp[1];
+            const u64 a[4] = {(u64)qlo.x | ((u64)qlo.y << 32), (u64)qlo.z | ((u64)qlo.w << 32),
+                              (u64)qhi.x | ((u64)qhi.y << 32), (u64)qhi.z | ((u64)qhi.w << 32)};
+            // the epipolar line of kp1 in image 2 (Pinhole::epipolarConstrain_, Pinhole.cpp:281-287)
+            const float la = kp1.x * P.F12[0] + kp1.y * P.F12[3] + P.F12[6];
+            const float lb = kp1.x * P.F12[1] + kp1.y * P.F12[4] + P.F12[7];
+            const float lc = kp1.x * P.F12[2] + kp1.y * P.F12[5] + P.F12[8];
+            const float den = la * la + lb * lb;
+            const int c0 = bStart[(size_t)pair * 257 + (nd & 255)], c1 = bStart[(size_t)pair * 257 + (nd & 255) + 1];
+            for (int ci = c0; ci < c1; ++ci) {
+                const int i2 = (int)bIdx[o + ci];
+                if (node2[o + i2] != nd) continue;
+                const bool bStereo2 = ur2 && ur2[o + i2] >= 0;
+                if (P.onlyStereo && !bStereo2) continue;
+                const uint4* tp = (const uint4*)(desc2 + (o + i2) * 32);
+                const uint4 lo = tp[0], hi = tp[1];
+                const int d = ham256(a, (u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
+                                     (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32));
+                if (d > 50) continue;                                                // TH_LOW
+                const KpIn kp2 = kps2[o + i2];
+                if (!bStereo1 && !bStereo2) {
+                    const float distex = P.epx - kp2.x, distey = P.epy - kp2.y;
+                    if (distex * distex + distey * distey < 100 * P.sf2[kp2.octave]) continue;
+                }
+                bool epi = false;
+                if (den != 0) {
+                    const float num = la * kp2.x + lb * kp2.y + lc;
+                    const float dsqr = num * num / den;
+                    epi = (double)dsqr < 3.84 * (double)P.sigma2[kp2.octave];         // float compared with the double product, as written (Pinhole.cpp:295)
+                }
+                if (epi || P.coarse) best = min(best, ((unsigned)d << 16) | (0xFFFFu - (unsigned)i2));
             }
-            bool epi = false;
-            if (den != 0) {
-                const float num = la * kp2.x + lb * kp2.y + lc;
-                const float dsqr = num * num / den;
-                epi = (double)dsqr < 3.84 * (double)P.sigma2[kp2.octave];         // float compared with the double product, as written (Pinhole.cpp:295)
-            }
-            if (epi || P.coarse) best = min(best, ((unsigned)d << 16) | (0xFFFFu - (unsigned)i2));
         }
-    }
-#pragma unroll
-    for (int s_ = 32; s_ > 0; s_ >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, s_));
-    if (lane == 0) {
-        const int res = best == 0xFFFFFFFFu ? -1 : (int)(0xFFFFu - (best & 0xFFFFu));
+        res = best == 0xFFFFFFFFu ? -1 : (int)(0xFFFFu - (best & 0xFFFFu));
         matches12[o + i1] = res;
-        if (res >= 0) atomicAdd(&nmatches[pair], 1);
     }
+    const unsigned long long found = __ballot(res >= 0);
+    if ((threadIdx.x & 63) == 0 && found) atomicAdd(&nmatches[pair], __popcll(found));
 }
 
 // ------------------------------------------------------------------------------------------------
