@@ -41,3 +41,16 @@ for l in range(8):
     #assert not (corner & ~q4).any() and not (corner & ~q8).any() and not (corner&~q8b).any()
     tot['px']+=n; tot['q4']+=q4.sum(); tot['q8']+=q8.sum(); tot['q8b']+=q8b.sum(); tot['corner']+=corner.sum()
 print({k:(v/tot['px'] if k!='px' else v) for k,v in tot.items()})
+
+# ---- polarity of the 4-point survivors: dark-only / bright-only / both (a single-polarity score network would need two passes for "both")
+tot2 = dict(q4=0, dark_only=0, bright_only=0, both=0)
+for l in range(8):
+    L = ref.level_image(l).astype(np.int32)
+    h, w = L.shape
+    v = L[3:h-3, 3:w-3]
+    R = {k: L[3+dy:h-3+dy, 3+dx:w-3+dx] for k, (dx, dy) in enumerate(ring) if k in (0, 4, 8, 12)}
+    t = 20
+    D = ((R[0] < v - t) | (R[8] < v - t)) & ((R[4] < v - t) | (R[12] < v - t))
+    B = ((R[0] > v + t) | (R[8] > v + t)) & ((R[4] > v + t) | (R[12] > v + t))
+    tot2['q4'] += int((D | B).sum()); tot2['dark_only'] += int((D & ~B).sum()); tot2['bright_only'] += int((B & ~D).sum()); tot2['both'] += int((D & B).sum())
+print("polarity of 4-point survivors:", {k: round(v / tot2['q4'], 4) for k, v in tot2.items()})
