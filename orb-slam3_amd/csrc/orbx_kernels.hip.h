@@ -1657,6 +1657,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(Geom g, const u8* const* l0
 //    descriptor bytes 2q and 2q+1 already in LSB-first bit order (bit s of the group's 16-bit field).
 //    The 512 pattern points sit in LDS as floats (staged once per workgroup).
 // ------------------------------------------------------------------------------------------------
+#ifndef OD_WIDE
+#define OD_WIDE 1
+#endif
 #define OD_PPITCH 40
 #define OD_WTAB (17 * 8)                                   // IC_Angle weight table: [|v| (16 = zero row)][dword of the 32-byte patch row]
 #define OD_PATCH (37 * OD_PPITCH)
@@ -1666,7 +1669,7 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
                                                       const int8_t* __restrict__ pattern, const u32* __restrict__ odw) {
     __shared__ float4 spat[256];                               // (x0, y0, x1, y1) per pair
     __shared__ __attribute__((aligned(16))) u8 bpatch[16 * OD_PATCH];   // blurred 37 x 40-byte patch of each of the 16 keypoints
-    __shared__ u32 sW[OD_WTAB];                                // IC_Angle byte weights (see orbx_create)
+    __shared__ __attribute__((aligned(8))) u32 sW[OD_WTAB];   // IC_Angle byte weights (see orbx_create)
     const int tid = threadIdx.x;
     {
         for (int i = tid; i < OD_WTAB; i += 256) sW[i] = odw[i];
@@ -1686,6 +1689,84 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
     // ---- orientation: all 64 lanes work on one keypoint's 31 x 8 dwords at a time; the 4 x 4 loads of the whole
     // wave are issued before any arithmetic (one memory round trip instead of four)
     int m10s[4] = {0, 0, 0, 0}, m01s[4] = {0, 0, 0, 0};
+#if OD_WIDE
+    // 8-byte pieces (unaligned dwordx2 loads): 31 x 4 pieces of the unblurred rows + 37 x 5 of the blurred ones = 5 load
+    // instructions per keypoint instead of 10 -- the kernel is bound by the texture addresser's per-lane work, not by bytes
+    uint2 dq[4][2], bq[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) dq[k][it] = make_uint2(0, 0);
+#pragma unroll
+        for (int it = 0; it < 3; ++it) bq[k][it] = make_uint2(0, 0);
+        if (base + k < n) {                                     // wave-uniform
+            const int level = __builtin_amdgcn_readlane((int)w.level, 16 * k);
+            const int cx = __builtin_amdgcn_readlane((int)w.x, 16 * k);
+            const int cy = __builtin_amdgcn_readlane((int)w.y, 16 * k);
+            int sp;
+            const u8* im = level_ptr(g, l0, l0pitch, pyr, frame, level, &sp);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int idx = it * 64 + lane;
+                const int r = idx >> 2, j = idx & 3;
+                if (r < 31) dq[k][it] = gload64u_unaligned(im, (u32)(__mul24(cy + r - 15, sp) + cx - 15 + 8 * j));
+            }
+            const LevelDesc& Lk = g.lv[level];
+            const u8* bl = blr + (size_t)frame * g.pyrFrameBytes + Lk.off;
+            const int xalb = (cx - 18) & ~3;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int idx = it * 64 + lane;
+                const int r = (idx * 205) >> 10;                // idx / 5 for idx < 192
+                const int j = idx - r * 5;
+                if (r < 37) bq[k][it] = gload64u_unaligned(bl, (u32)(__mul24(cy + r - 18, Lk.pitch) + xalb + 8 * j));
+            }
+        }
+    }
+    {   // park the blurred patches in LDS (each wave owns 4 patches; same-wave LDS traffic needs no barrier): piece idx sits at byte 8 idx
+        u8* mine = bpatch + (threadIdx.x >> 6) * 4 * OD_PATCH;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int idx = it * 64 + lane;
+                if (idx < 185) *(uint2*)(mine + k * OD_PATCH + idx * 8) = bq[k][it];
+            }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int bxoff = w.x - ((w.x - 18) & ~3);                  // column of the keypoint inside its patch
+    int tbl[2], vrow[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = it * 64 + lane;
+        const int v = (idx >> 2) - 15;
+        vrow[it] = v;
+        tbl[it] = min(v < 0 ? -v : v, 16) * 8 + 2 * (idx & 3);  // the two dwords (2j, 2j+1) of the 32-byte patch row
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) {
+            u32 a1 = 0, a2 = 0;
+            int m01 = 0;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const uint2 w1 = *(const uint2*)&sW[tbl[it]];
+                const u32 w2x = ((w1.x + 0x7F7F7F7Fu) & 0x80808080u) >> 7, w2y = ((w1.y + 0x7F7F7F7Fu) & 0x80808080u) >> 7;
+                a1 = __builtin_amdgcn_udot4(dq[k][it].x, w1.x, a1, false);
+                a1 = __builtin_amdgcn_udot4(dq[k][it].y, w1.y, a1, false);
+                u32 s2 = __builtin_amdgcn_udot4(dq[k][it].x, w2x, 0u, false);
+                s2 = __builtin_amdgcn_udot4(dq[k][it].y, w2y, s2, false);
+                a2 += s2;
+                m01 += __mul24(vrow[it], (int)s2);
+            }
+            int m10 = (int)a1 - 16 * (int)a2;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+            m10s[k] = m10; m01s[k] = m01;
+        }
+    }
+#else
     u32 dq[4][4], bq[4][6];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1763,6 +1844,7 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
             m10s[k] = m10; m01s[k] = m01;
         }
     }
+#endif
     const int m10 = sub == 0 ? m10s[0] : sub == 1 ? m10s[1] : sub == 2 ? m10s[2] : m10s[3];
     const int m01 = sub == 0 ? m01s[0] : sub == 1 ? m01s[1] : sub == 2 ? m01s[2] : m01s[3];
     const float angle = fast_atan2_deg((float)m01, (float)m10);
