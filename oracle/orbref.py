@@ -16,6 +16,8 @@ assert KP_DTYPE.itemsize == 28
 
 
 def build(force=False):
+    if os.environ.get("ORBREF_LIB"):           # tests/test_oracle_sanitize.py: an ASan/UBSan build of the same sources
+        return os.environ["ORBREF_LIB"]
     so = os.path.join(_HERE, "liborbref.so")
     if force or not os.path.exists(so):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
