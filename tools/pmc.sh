@@ -4,7 +4,7 @@
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/$out
-rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 --batch 128 --launch eager $PMC_BENCH_ARGS > $GRAFT_REPO_ROOT/gpurun_out/$out.log 2>&1
+timeout -k 10 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 --batch 128 --launch eager $PMC_BENCH_ARGS > $GRAFT_REPO_ROOT/gpurun_out/$out.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob('$GRAFT_REPO_ROOT/gpurun_out/$out/*/*counter_collection.csv')[0]
