@@ -68,6 +68,7 @@ struct orbx {
     size_t qtLds = 0, qt2Lds = 0;
     int qt2Cap = 0, qt2Sort = 0;
     bool qtV1 = false, odV1 = false, serial = false, blurV2 = false, blurEarly = true;
+    bool blurTiled = true;                                     // k_blur3 writes / k_orient_desc2 reads the blurred levels as 16 x 8-px tiles (ORBX_BLUR_ROWMAJOR: A/B)
     bool qtWide = false;                                       // 1024-thread quadtree workgroups (large frames / feature counts)
     int qtWideForce = -1;                                      // ORBX_QT_WIDE=0/1: A/B switch
     // device
@@ -180,7 +181,7 @@ static int build_geometry(orbx* o, int w, int h) {
     g.nlevels = L; g.w0 = w; g.h0 = h; g.iniTh = o->iniTh; g.minTh = o->minTh; g.lowTh = std::min(o->iniTh, o->minTh);
     std::vector<Blur3Task> tiles3one;                         // one-tile k_blur3 tasks, appended behind the walks
     o->cells.clear(); o->tiles.clear(); o->tiles3.clear(); o->b3Th.clear(); o->b3Tv.clear(); o->strips.clear(); o->f3g.clear(); o->stripTile.clear(); o->stripQ.clear(); o->xt.clear(); o->yt.clear(); o->x4.clear(); for (auto& v : o->rzTasks) v.clear();
-    size_t off = 0;
+    size_t off = 0, boff = 0;
     int totalSlots = 0, totalSel = 0, maxN = 0;
     int64_t sumAll = 0, sumSrc = 0, sumDst = 0;
     for (int l = 0; l < L; ++l) {
@@ -191,6 +192,11 @@ static int build_geometry(orbx* o, int w, int h) {
         D.pitch = align_up(D.w, 64);
         D.off = (int)off;
         off += (size_t)align_up(D.pitch * D.h, 256);
+        // blurred copy: row-major twin of the level, or 16 x 8-px tiles (one more tile per tile row than the pitch needs: the
+        // descriptor kernel's 48-byte patch rows may start up to 10 bytes before the right edge)
+        D.btpr = D.pitch / 16 + 1;
+        D.boff = o->blurTiled ? (int)boff : D.off;
+        boff += (size_t)align_up(D.btpr * ((D.h + 7) / 8) * 128, 256);
         D.sf = o->sf[l];
         D.patch = (float)(int)(31 * o->sf[l]);
         D.N = o->nfeat[l];
@@ -368,6 +374,8 @@ static int build_geometry(orbx* o, int w, int h) {
         while (o->xt.size() % 4) o->xt.push_back(RzTab{0, 0, 0});      // keep every level's tap offset a multiple of 4
     }
     g.pyrFrameBytes = off;
+    g.blurTiled = o->blurTiled ? 1 : 0;
+    g.blrFrameBytes = o->blurTiled ? boff : off;
     g.totalCells = (int)o->cells.size();
     g.totalSlots = totalSlots;
     g.totalSel = totalSel;
@@ -394,7 +402,7 @@ static int build_geometry(orbx* o, int w, int h) {
 
     const size_t B = (size_t)o->maxBatch;
     if (ensure(&o->dPyr, &o->capPyr, off * B)) return ORBX_E_HIP;
-    { size_t c2 = 0; u8* old = o->dBlur; if (old) (void)hipFree(old); o->dBlur = nullptr; if (ensure(&o->dBlur, &c2, off * B)) return ORBX_E_HIP; }
+    { size_t c2 = 0; u8* old = o->dBlur; if (old) (void)hipFree(old); o->dBlur = nullptr; if (ensure(&o->dBlur, &c2, g.blrFrameBytes * B)) return ORBX_E_HIP; }
     if (ensure(&o->dL0, &o->capL0, (size_t)o->l0pitch * h * B)) return ORBX_E_HIP;
     if (ensure(&o->dCells, &o->capCells, o->cells.size())) return ORBX_E_HIP;
     if (ensure(&o->dTiles, &o->capTiles, o->tiles.size())) return ORBX_E_HIP;
@@ -603,6 +611,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     o->f3NoFixedPitch = getenv("ORBX_FAST_PITCH0") != nullptr;
     if (const char* e = getenv("ORBX_QT_WIDE")) o->qtWideForce = atoi(e) != 0 ? 1 : 0;
     o->blurEarly = !o->blurV2 && getenv("ORBX_BLUR_LATE") == nullptr;
+    o->blurTiled = !o->blurV2 && !o->odV1 && getenv("ORBX_BLUR_ROWMAJOR") == nullptr;
     o->dlKernel = getenv("ORBX_DL_KERNEL") != nullptr;          // A/B: results-to-host copy by k_copy_out instead of the copy engine
     if (const char* e = getenv("ORBX_DL_GRID")) o->dlGrid = std::max(1, atoi(e));
     o->serial = getenv("ORBX_SERIAL") != nullptr;            // A/B switch: simple per-cell reference kernel
@@ -1136,7 +1145,16 @@ int orbx_level_image(orbx_t* o, int frame, int level, int blurred, uint8_t* dst,
         HIPCHK(hipMemcpy2D(dst, dst_stride, src, pitch, D.w, D.h, hipMemcpyDeviceToHost));
         return ORBX_OK;
     }
-    const u8* base = (blurred ? o->dBlur : o->dPyr) + (size_t)frame * o->g.pyrFrameBytes + D.off;
+    if (blurred && o->g.blurTiled) {                             // de-tile on the host (a debug / test accessor)
+        const size_t nb = (size_t)D.btpr * ((D.h + 7) / 8) * 128;
+        std::vector<u8> raw(nb);
+        HIPCHK(hipMemcpy(raw.data(), o->dBlur + (size_t)frame * o->g.blrFrameBytes + D.boff, nb, hipMemcpyDeviceToHost));
+        for (int y = 0; y < D.h; ++y)
+            for (int x = 0; x < D.w; ++x)
+                dst[(size_t)y * dst_stride + x] = raw[((size_t)(y >> 3) * D.btpr + (x >> 4)) * 128 + (size_t)(y & 7) * 16 + (x & 15)];
+        return ORBX_OK;
+    }
+    const u8* base = blurred ? o->dBlur + (size_t)frame * o->g.blrFrameBytes + D.boff : o->dPyr + (size_t)frame * o->g.pyrFrameBytes + D.off;
     HIPCHK(hipMemcpy2D(dst, dst_stride, base, D.pitch, D.w, D.h, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }

@@ -29,6 +29,7 @@ struct RzTab { int s; short a0, a1; };                     // source index + two
 struct LevelDesc {                                         // one pyramid level of the current geometry
     int w, h, pitch;
     int off;                                               // byte offset inside a frame's pyramid slab (levels >= 1)
+    int boff, btpr;                                        // blurred copy: byte offset inside a frame's blurred slab; tiles per tile row (tiled layout)
     int rzx, rzy;                                          // offsets into the resize tap tables
     int cellBase, nCells;                                  // active FAST cells of this level in the cell table
     int slotBase, slotCap;                                 // candidate slots: slotBase + cell*slotCap + k
@@ -53,6 +54,8 @@ struct Geom {                                              // kernel argument bl
     int totalCells, totalSlots, totalSel, kpCap;
     int nodeCap, sortCap;
     size_t pyrFrameBytes;                                  // per-frame slab holding levels 1..L-1 (and a copy slot for 0)
+    size_t blrFrameBytes;                                  // per-frame slab of the blurred levels
+    int blurTiled;                                         // blurred levels are stored as 16 x 8-px tiles (one 128-byte line each), see k_blur3
     LevelDesc lv[12];
 };
 
@@ -1363,7 +1366,7 @@ __global__ __launch_bounds__(256) void k_blur3(Geom g, const u8* const* l0, int 
     const LevelDesc& L = g.lv[t.level];
     int sp;
     const u8* im = level_ptr(g, l0, l0pitch, pyr, frame, t.level, &sp);
-    u8* dst = blr + (size_t)frame * g.pyrFrameBytes + L.off;
+    u8* dst = blr + (size_t)frame * g.blrFrameBytes + L.boff;
     const int w = L.w, h = L.h, dp = L.pitch, xg = t.x0, x0 = xg + 32 * cb;
     const bool live = x0 < w;                                           // wave-uniform: a block past the right edge only helps loading
     const int r = lane & 31, hh = lane >> 5;
@@ -1408,11 +1411,20 @@ __global__ __launch_bounds__(256) void k_blur3(Geom g, const u8* const* l0, int 
 #pragma unroll
     for (int i = 0; i < 16; ++i) c2[i] = 256 * 32768 + 32768 + 32768;
     // write-out: the workgroup's 26 x 128 px tile leaves as 16-byte pieces, 8 per row: full 128-byte lines per row
-    const int orow = tid >> 3, oseg = tid & 7;
+    // (tiled output: 8 consecutive lanes take 8 consecutive rows of one 16-byte column = one tile's line when the rows are aligned)
+    const bool tiledOut = g.blurTiled != 0;
+    const int orow = tiledOut ? (tid & 7) + 8 * (tid >> 6) : tid >> 3, oseg = tiledOut ? (tid >> 3) & 7 : tid & 7;
     const bool ocol = xg + 16 * oseg < w && orow < B3_ROWS;
     const int obR = orow * B3_OROW + 16 * oseg;
     int hrem = h - t.t0 * B3_ROWS - orow;                                          // > 0: this thread's output row is inside the image
-    u32 so = (u32)((t.t0 * B3_ROWS + orow) * dp + xg + 16 * oseg);
+    // Tiled output (g.blurTiled): the blurred level is only ever read back as 37-row x 40-byte patches around keypoints
+    // (k_orient_desc2), and that gather is bound by the number of 128-byte lines it touches: as 16 x 8-px tiles of one line each
+    // a patch covers ~21 lines instead of ~48.  Piece (row y, 16-byte column c) lives at ((y >> 3) * btpr + c) * 128 + (y & 7) * 16;
+    // the 8 rows x 8 pieces a wave stores are still whole or half lines (L2 merges the halves of a tile written by two steps).
+    const bool tiled = tiledOut;
+    int yo = t.t0 * B3_ROWS + orow;
+    const u32 tcol = (u32)(((xg >> 4) + oseg) << 7);
+    u32 so = (u32)(yo * dp + xg + 16 * oseg);
     const u32 sstep = (u32)(B3_ROWS * dp);
     for (int k = 0; k < t.nt; ++k) {
         const int buf = k & 1;
@@ -1465,9 +1477,10 @@ __global__ __launch_bounds__(256) void k_blur3(Geom g, const u8* const* l0, int 
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (ocol && hrem > 0) {
             const uint4 v = *(const uint4*)(ob[buf] + obR);
-            *(__attribute__((address_space(1))) uint4*)((__attribute__((address_space(1))) u8*)dst + so) = v;
+            const u32 sa = tiled ? (u32)(__mul24(yo >> 3, L.btpr) << 7) + tcol + (u32)((yo & 7) << 4) : so;
+            *(__attribute__((address_space(1))) uint4*)((__attribute__((address_space(1))) u8*)dst + sa) = v;
         }
-        hrem -= B3_ROWS; so += sstep;
+        hrem -= B3_ROWS; so += sstep; yo += B3_ROWS;
     }
 #endif
 }
@@ -1490,7 +1503,7 @@ __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int 
     const LevelDesc& L = g.lv[t.level];
     int sp;
     const u8* im = level_ptr(g, l0, l0pitch, pyr, frame, t.level, &sp);
-    u8* dst = blr + (size_t)frame * g.pyrFrameBytes + L.off;
+    u8* dst = blr + (size_t)frame * g.blrFrameBytes + L.boff;
     const int w = L.w, h = L.h;
     const int gl = (w - 1) >> 2;                           // last dword column holding image pixels
     // lanes 0 and 63 are halo lanes (they load and filter but do not store) -- except at the image's own left / right edge,
@@ -1579,18 +1592,19 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
                 p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
     const float eps = (float)2.2204460492503131e-16;
     const float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = ay / (ax + eps); c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    } else {
-        c = ax / (ay + eps); c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    }
+    // branch-free: both branches of cv::fastAtan2 divide the smaller by (the larger + eps) and run the same polynomial; one IEEE
+    // division per call instead of two when the keypoints of a wave disagree about the branch
+    const bool xbig = ax >= ay;
+    const float c = (xbig ? ay : ax) / ((xbig ? ax : ay) + eps), c2 = c * c;
+    const float pl = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    float a = xbig ? pl : 90.f - pl;
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
     return a;
 }
+
+#define OD_FN __device__ __forceinline__
+#include "od_sincos.h"
 
 struct Umax { int v[16]; };
 
@@ -1620,7 +1634,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(Geom g, const u8* const* l0
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     // descriptor
     const LevelDesc& L = g.lv[w.level];
-    const u8* bc = blr + (size_t)frame * g.pyrFrameBytes + L.off + (size_t)w.y * L.pitch + w.x;
+    const u8* bc = blr + (size_t)frame * g.blrFrameBytes + L.boff + (size_t)w.y * L.pitch + w.x;
     const int bp = L.pitch;
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ar = angle * factorPI;
@@ -1657,28 +1671,25 @@ __global__ __launch_bounds__(256) void k_orient_desc(Geom g, const u8* const* l0
 //    descriptor bytes 2q and 2q+1 already in LSB-first bit order (bit s of the group's 16-bit field).
 //    The 512 pattern points sit in LDS as floats (staged once per workgroup).
 // ------------------------------------------------------------------------------------------------
-#ifndef OD_WIDE
-#define OD_WIDE 1
-#endif
 #ifndef OD_XCD
 #define OD_XCD 1
 #endif
 #define OD_PPITCH 40
+#define OD_PPITCH_T 48                                     // tiled blurred level: 6 aligned 8-byte pieces per patch row
 #define OD_WTAB (17 * 8)                                   // IC_Angle weight table: [|v| (16 = zero row)][dword of the 32-byte patch row]
 #define OD_PATCH (37 * OD_PPITCH)
+#define OD_PATCH_T (37 * OD_PPITCH_T)
 __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
                                                       const u8* blr, const KpWork* __restrict__ work,
                                                       const int* __restrict__ nOut, KpOut* kps, u8* desc,
                                                       const int8_t* __restrict__ pattern, const u32* __restrict__ odw) {
-    __shared__ float4 spat[256];                               // (x0, y0, x1, y1) per pair
-    __shared__ __attribute__((aligned(16))) u8 bpatch[16 * OD_PATCH];   // blurred 37 x 40-byte patch of each of the 16 keypoints
+    __shared__ u32 spat[256];                                  // (x0, y0, x1, y1) per pair, int8 each (converted on use: 1 KB instead of 4 keeps 5 workgroups per CU)
+    __shared__ __attribute__((aligned(16))) u8 bpatch[16 * OD_PATCH_T];   // blurred 37-row patch of each of the 16 keypoints (40- or 48-byte rows)
     __shared__ __attribute__((aligned(8))) u32 sW[OD_WTAB];   // IC_Angle byte weights (see orbx_create)
     const int tid = threadIdx.x;
     {
         for (int i = tid; i < OD_WTAB; i += 256) sW[i] = odw[i];
-        const int raw = ((const int*)pattern)[tid];
-        spat[tid] = make_float4((float)(int8_t)(raw & 0xFF), (float)(int8_t)((raw >> 8) & 0xFF),
-                                (float)(int8_t)((raw >> 16) & 0xFF), (float)(int8_t)((raw >> 24) & 0xFF));
+        spat[tid] = ((const u32*)pattern)[tid];
     }
     __syncthreads();
 #if OD_XCD
@@ -1704,16 +1715,16 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
     // ---- orientation: all 64 lanes work on one keypoint's 31 x 8 dwords at a time; the 4 x 4 loads of the whole
     // wave are issued before any arithmetic (one memory round trip instead of four)
     int m10s[4] = {0, 0, 0, 0}, m01s[4] = {0, 0, 0, 0};
-#if OD_WIDE
     // 8-byte pieces (unaligned dwordx2 loads): 31 x 4 pieces of the unblurred rows + 37 x 5 of the blurred ones = 5 load
     // instructions per keypoint instead of 10 (same bytes; worth 1.5 %: the kernel is bound by the lines it misses in L2)
-    uint2 dq[4][2], bq[4][3];
+    const bool tiled = g.blurTiled != 0;                        // wave-uniform
+    uint2 dq[4][2], bq[4][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) dq[k][it] = make_uint2(0, 0);
 #pragma unroll
-        for (int it = 0; it < 3; ++it) bq[k][it] = make_uint2(0, 0);
+        for (int it = 0; it < 4; ++it) bq[k][it] = make_uint2(0, 0);
         if (base + k < n) {                                     // wave-uniform
             const int level = __builtin_amdgcn_readlane((int)w.level, 16 * k);
             const int cx = __builtin_amdgcn_readlane((int)w.x, 16 * k);
@@ -1727,30 +1738,44 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
                 if (r < 31) dq[k][it] = gload64u_unaligned(im, (u32)(__mul24(cy + r - 15, sp) + cx - 15 + 8 * j));
             }
             const LevelDesc& Lk = g.lv[level];
-            const u8* bl = blr + (size_t)frame * g.pyrFrameBytes + Lk.off;
-            const int xalb = (cx - 18) & ~3;
+            const u8* bl = blr + (size_t)frame * g.blrFrameBytes + Lk.boff;
+            if (tiled) {
+                // rows cy-18..cy+18, six 8-byte pieces from (cx-18) & ~7 (each inside one 16-byte tile row): 37 x 6 = 222 pieces
+                const int xal8 = (cx - 18) & ~7;
 #pragma unroll
-            for (int it = 0; it < 3; ++it) {
-                const int idx = it * 64 + lane;
-                const int r = (idx * 205) >> 10;                // idx / 5 for idx < 192
-                const int j = idx - r * 5;
-                if (r < 37) bq[k][it] = gload64u_unaligned(bl, (u32)(__mul24(cy + r - 18, Lk.pitch) + xalb + 8 * j));
+                for (int it = 0; it < 4; ++it) {
+                    const int idx = it * 64 + lane;
+                    const int r = (idx * 171) >> 10;            // idx / 6 for idx < 256
+                    const int yy = cy + r - 18, xx = xal8 + 8 * (idx - r * 6);
+                    if (r < 37) bq[k][it] = gload64u_unaligned(bl, (u32)(((__mul24(yy >> 3, Lk.btpr) + (xx >> 4)) << 7) + ((yy & 7) << 4) + (xx & 15)));
+                }
+            } else {
+                const int xalb = (cx - 18) & ~3;
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    const int idx = it * 64 + lane;
+                    const int r = (idx * 205) >> 10;            // idx / 5 for idx < 192
+                    const int j = idx - r * 5;
+                    if (r < 37) bq[k][it] = gload64u_unaligned(bl, (u32)(__mul24(cy + r - 18, Lk.pitch) + xalb + 8 * j));
+                }
             }
         }
     }
+    const int ppitch = tiled ? OD_PPITCH_T : OD_PPITCH;
     {   // park the blurred patches in LDS (each wave owns 4 patches; same-wave LDS traffic needs no barrier): piece idx sits at byte 8 idx
-        u8* mine = bpatch + (threadIdx.x >> 6) * 4 * OD_PATCH;
+        u8* mine = bpatch + (threadIdx.x >> 6) * 4 * OD_PATCH_T;
+        const int npc = tiled ? 222 : 185;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int it = 0; it < 3; ++it) {
+            for (int it = 0; it < 4; ++it) {
                 const int idx = it * 64 + lane;
-                if (idx < 185) *(uint2*)(mine + k * OD_PATCH + idx * 8) = bq[k][it];
+                if (idx < npc) *(uint2*)(mine + k * OD_PATCH_T + idx * 8) = bq[k][it];
             }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const int bxoff = w.x - ((w.x - 18) & ~3);                  // column of the keypoint inside its patch
+    const int bxoff = w.x - ((w.x - 18) & (tiled ? ~7 : ~3));   // column of the keypoint inside its patch
     int tbl[2], vrow[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -1781,102 +1806,26 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
             m10s[k] = m10; m01s[k] = m01;
         }
     }
-#else
-    u32 dq[4][4], bq[4][6];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) dq[k][it] = 0;
-#pragma unroll
-        for (int it = 0; it < 6; ++it) bq[k][it] = 0;
-        if (base + k < n) {                                     // wave-uniform
-            const int level = __builtin_amdgcn_readlane((int)w.level, 16 * k);
-            const int cx = __builtin_amdgcn_readlane((int)w.x, 16 * k);
-            const int cy = __builtin_amdgcn_readlane((int)w.y, 16 * k);
-            int sp;
-            const u8* im = level_ptr(g, l0, l0pitch, pyr, frame, level, &sp);
-            // 31 rows x 8 dwords starting exactly at cx-15 (global loads take any byte alignment): 248 dwords = 4 per lane
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int idx = it * 64 + lane;
-                const int r = idx >> 3, j = idx & 7;
-                if (r < 31) dq[k][it] = gload32u(im, (u32)(__mul24(cy + r - 15, sp) + cx - 15 + 4 * j));
-            }
-            // blurred patch: rows cy-18..cy+18, 10 aligned dwords from (cx-18)&~3
-            const LevelDesc& Lk = g.lv[level];
-            const u8* bl = blr + (size_t)frame * g.pyrFrameBytes + Lk.off;
-            const int xalb = (cx - 18) & ~3;
-#pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                const int idx = it * 64 + lane;
-                const int r = (idx * 205) >> 11;                // idx / 10 for idx < 384
-                const int j = idx - r * 10;
-                if (r < 37) bq[k][it] = gload32u(bl, (u32)(__mul24(cy + r - 18, Lk.pitch) + xalb + 4 * j));
-            }
-        }
-    }
-    {   // park the blurred patches in LDS (each wave owns 4 patches; same-wave LDS traffic needs no barrier)
-        u8* mine = bpatch + (threadIdx.x >> 6) * 4 * OD_PATCH;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                const int idx = it * 64 + lane;
-                if (idx < 370) *(u32*)(mine + k * OD_PATCH + idx * 4) = bq[k][it];
-            }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int bxoff = w.x - ((w.x - 18) & ~3);                  // column of the keypoint inside its patch
-    // IC_Angle moments with v_dot4: per patch dword  S1 = sum (u+16)*I over the disc, S2 = sum I over the disc;
-    // m10 = S1 - 16*S2, m01 = sum over rows of v*S2.  The weights come from LDS ([alignment][|v|][dword]); the in-disc
-    // 0/1 bytes are the non-zero bytes of the weight word (u + 16 >= 1 inside the disc).
-    int tbl[4], vrow[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int idx = it * 64 + lane;
-        const int v = (idx >> 3) - 15;
-        vrow[it] = v;
-        tbl[it] = min(v < 0 ? -v : v, 16) * 8 + (idx & 7);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (base + k < n) {
-            u32 a1 = 0, a2 = 0;
-            int m01 = 0;
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const u32 w1 = sW[tbl[it]];
-                const u32 w2 = ((w1 + 0x7F7F7F7Fu) & 0x80808080u) >> 7;
-                a1 = __builtin_amdgcn_udot4(dq[k][it], w1, a1, false);
-                const u32 s2 = __builtin_amdgcn_udot4(dq[k][it], w2, 0u, false);
-                a2 += s2;
-                m01 += __mul24(vrow[it], (int)s2);
-            }
-            int m10 = (int)a1 - 16 * (int)a2;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
-            m10s[k] = m10; m01s[k] = m01;
-        }
-    }
-#endif
     const int m10 = sub == 0 ? m10s[0] : sub == 1 ? m10s[1] : sub == 2 ? m10s[2] : m10s[3];
     const int m01 = sub == 0 ? m01s[0] : sub == 1 ? m01s[1] : sub == 2 ? m01s[2] : m01s[3];
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ar = angle * factorPI;
     double sd, cd;
-    sincos((double)ar, &sd, &cd);                               // one range reduction for both (same kernels as sin / cos)
+    od_sincos(ar, &sd, &cd);                                    // ar in [0, 2 pi] (fastAtan2 returns [0, 360]); checked against libm on every float
     const float a = (float)cd, b = (float)sd;
     // ---- descriptor: 16 pairs per lane, sampled from the LDS copy of the keypoint's 37-row blurred patch (the patch
     // rows were requested together with the orientation rows: one global round trip per wave instead of two)
-    const u8* pc = bpatch + ((threadIdx.x >> 6) * 4 + sub) * OD_PATCH + 18 * OD_PPITCH + bxoff;
+    const u8* pc = bpatch + ((threadIdx.x >> 6) * 4 + sub) * OD_PATCH_T + 18 * ppitch + bxoff;
     u8 t0[16], t1[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const float4 pt = spat[q * 16 + sl];
-        const int o0 = __mul24(__float2int_rn(pt.x * b + pt.y * a), OD_PPITCH) + __float2int_rn(pt.x * a - pt.y * b);   // 24-bit multiplies: full rate
-        const int o1 = __mul24(__float2int_rn(pt.z * b + pt.w * a), OD_PPITCH) + __float2int_rn(pt.z * a - pt.w * b);
+        const u32 raw = spat[q * 16 + sl];
+        float4 pt;
+        pt.x = (float)(int)(int8_t)(raw & 0xFF); pt.y = (float)(int)(int8_t)((raw >> 8) & 0xFF);
+        pt.z = (float)(int)(int8_t)((raw >> 16) & 0xFF); pt.w = (float)((int)raw >> 24);
+        const int o0 = __mul24(__float2int_rn(pt.x * b + pt.y * a), ppitch) + __float2int_rn(pt.x * a - pt.y * b);   // 24-bit multiplies: full rate
+        const int o1 = __mul24(__float2int_rn(pt.z * b + pt.w * a), ppitch) + __float2int_rn(pt.z * a - pt.w * b);
         t0[q] = valid ? pc[o0] : (u8)0;
         t1[q] = valid ? pc[o1] : (u8)0;
     }
