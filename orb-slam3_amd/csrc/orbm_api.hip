@@ -119,9 +119,11 @@ void* orbm_stream(const orbm_t* m) { return m ? (void*)m->stream : nullptr; }
 
 int orbm_set_stream(orbm_t* m, void* stream) {
     if (!m) return ORBM_E_INVALID;
+    hipStream_t ns = stream ? (hipStream_t)stream : m->ownStream;
+    if (ns == m->stream) return ORBM_OK;                        // nothing to drain (and safe while that stream is being captured)
     MHIPCHK(hipSetDevice(m->device));
     MHIPCHK(hipStreamSynchronize(m->stream));
-    m->stream = stream ? (hipStream_t)stream : m->ownStream;
+    m->stream = ns;
     return ORBM_OK;
 }
 
