@@ -1019,18 +1019,51 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
     const int nk = (int)block_scan_excl<NT>(cellOff, nCells, wsum, tid);
     if (tid == 0) cellOff[nCells] = (u32)nk;
     __syncthreads();
-    for (int i = tid; i < nk; i += NT) {
-        int lo = 0, hi = nCells;                             // last cell with cellOff <= i
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)cellOff[mid] <= i) lo = mid; else hi = mid; }
-        const u32 e = ents[lo * L.slotCap + (i - (int)cellOff[lo])];
-        de[i] = e;
-        const int root = (int)((float)(e & 0xFFF) / L.hX);  // ORBextractor.cc:740
-        kn[i] = (u16)root;
-        atomicAdd(&s1[root], 1u);
+    {   // four candidates per thread at a time: their (uniform-length, branch-free) searches for the last cell with cellOff <= i
+        // interleave, and so do the four loads of the entries
+        int top = 1;
+        while (top * 2 < nCells) top *= 2;                   // largest power of two < nCells (nCells >= 1)
+        for (int i0 = tid; i0 < nk; i0 += 4 * NT) {
+            int lo[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) lo[u] = 0;
+            for (int sft = top; sft > 0; sft >>= 1) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = min(i0 + u * NT, nk - 1), c = lo[u] + sft;
+                    if (c < nCells && (int)cellOff[c] <= i) lo[u] = c;
+                }
+            }
+            u32 e4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * NT, nk - 1); e4[u] = ents[lo[u] * L.slotCap + (i - (int)cellOff[lo[u]])]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * NT;
+                if (i < nk) {
+                    const u32 e = e4[u];
+                    de[i] = e;
+                    const int root = (int)((float)(e & 0xFFF) / L.hX);  // ORBextractor.cc:740
+                    kn[i] = (u16)root;
+                    atomicAdd(&s1[root], 1u);
+                }
+            }
+        }
     }
     __syncthreads();
 
-#define QT_FOR_KP(BODY) for (int ki = tid; ki < nk; ki += NT) { const u32 e = de[ki]; BODY }
+    // a pass over the level's candidates: the (entry, node) pairs of QT_U candidates per thread are requested together before any
+    // is processed -- a rolled loop pays one L2 round trip per candidate (the LDS atomics in the bodies keep the compiler from hoisting
+    // the next iteration's loads), and these passes are most of the kernel's time
+#ifndef QT_U
+#define QT_U 4
+#endif
+#define QT_FOR_KP(BODY) for (int k0_ = tid; k0_ < nk; k0_ += QT_U * NT) {                                         \
+        u32 e4_[QT_U]; int n4_[QT_U];                                                                                \
+        _Pragma("unroll") for (int u_ = 0; u_ < QT_U; ++u_) { const int ki = k0_ + u_ * NT; const bool in_ = ki < nk;  \
+            e4_[u_] = in_ ? de[ki] : 0u; n4_[u_] = in_ ? (int)kn[ki] : 0; }                                          \
+        _Pragma("unroll") for (int u_ = 0; u_ < QT_U; ++u_) { const int ki = k0_ + u_ * NT;                          \
+            if (ki < nk) { const u32 e = e4_[u_]; const int nd = n4_[u_]; BODY } } }
 
     // ---- roots (ORBextractor.cc:695-763)
     if (tid == 0) {
@@ -1045,7 +1078,7 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
         s_size = size; s_state = 0; s_seqBase = L.nIni; s_cnt = 0;
     }
     __syncthreads();
-    QT_FOR_KP({ (void)e; kn[ki] = newPos[kn[ki]]; })
+    QT_FOR_KP({ (void)e; kn[ki] = newPos[nd]; })
     __syncthreads();
 
     QNode* A = tabA; QNode* B = tabB;
@@ -1057,7 +1090,7 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
         for (int i = tid; i < size * 4; i += NT) qc[i] = 0;
         if (tid == 0) { s_cnt = 0; s_ncand = 0; }
         __syncthreads();
-        QT_FOR_KP({ const int nd = kn[ki]; if (A[nd].cnt > 1) atomicAdd(&qc[nd * 4 + qt_quadrant(A[nd].r, e & 0xFFF, (e >> 12) & 0xFFF)], 1u); })
+        QT_FOR_KP({ if (A[nd].cnt > 1) atomicAdd(&qc[nd * 4 + qt_quadrant(A[nd].r, e & 0xFFF, (e >> 12) & 0xFFF)], 1u); })
         __syncthreads();
         int totalCh = 0, newSize = 0;
         if (state == 0) {                                                    // ORBextractor.cc:779-895
@@ -1167,8 +1200,7 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
         }
         __syncthreads();
         // (3) relabel the keypoints
-        QT_FOR_KP({ const int nd = kn[ki];
-                    kn[ki] = proc[nd] ? childPos[nd * 4 + qt_quadrant(A[nd].r, e & 0xFFF, (e >> 12) & 0xFFF)] : newPos[nd]; })
+        QT_FOR_KP({ kn[ki] = proc[nd] ? childPos[nd * 4 + qt_quadrant(A[nd].r, e & 0xFFF, (e >> 12) & 0xFFF)] : newPos[nd]; })
         __syncthreads();
         if (tid == 0) {
             const int nToExpand = s_cnt;
@@ -1186,7 +1218,7 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
     u32* best = qc;
     for (int i = tid; i < nsel; i += NT) best[i] = 0;
     __syncthreads();
-    QT_FOR_KP({ atomicMax(&best[kn[ki]], ((e >> 24) << 24) | (0xFFFFFFu - (u32)ki)); })
+    QT_FOR_KP({ atomicMax(&best[nd], ((e >> 24) << 24) | (0xFFFFFFu - (u32)ki)); })
     __syncthreads();
     u32* so = selOut + (size_t)frame * g.totalSel + L.selBase;
     for (int i = tid; i < nsel; i += NT) {
