@@ -973,6 +973,38 @@ __device__ __forceinline__ u32 block_scan_excl(u32* a, int n, u32* wsum, int tid
     return total;
 }
 
+// two exclusive scans behind the same three barriers (the quadtree's iterations are barrier-latency bound)
+template <int NT>
+__device__ __forceinline__ void block_scan2_excl(u32* a1, int n1, u32* a2, int n2, u32* wsum, int tid, u32* tot1, u32* tot2) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const int per1 = (n1 + NT - 1) / NT, per2 = (n2 + NT - 1) / NT;
+    const int b1 = min(tid * per1, n1), e1 = min(b1 + per1, n1), b2 = min(tid * per2, n2), e2 = min(b2 + per2, n2);
+    u32 s1 = 0, s2 = 0;
+    for (int i = b1; i < e1; ++i) s1 += a1[i];
+    for (int i = b2; i < e2; ++i) s2 += a2[i];
+    u32 i1 = s1, i2 = s2;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t1 = __shfl_up(i1, o), t2 = __shfl_up(i2, o);
+        if (lane >= o) { i1 += t1; i2 += t2; }
+    }
+    __syncthreads();                                       // wsum may still be read from a previous call
+    if (lane == 63) { wsum[wv] = i1; wsum[NT / 64 + wv] = i2; }
+    __syncthreads();
+    u32 base1 = 0, base2 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) {
+        const u32 w1 = wsum[k], w2 = wsum[NT / 64 + k];
+        if (k < wv) { base1 += w1; base2 += w2; }
+        t1 += w1; t2 += w2;
+    }
+    u32 run1 = base1 + i1 - s1, run2 = base2 + i2 - s2;
+    for (int i = b1; i < e1; ++i) { const u32 v = a1[i]; a1[i] = run1; run1 += v; }
+    for (int i = b2; i < e2; ++i) { const u32 v = a2[i]; a2[i] = run2; run2 += v; }
+    __syncthreads();
+    *tot1 = t1; *tot2 = t2;
+}
+
 __device__ __forceinline__ short4 qt_child_rect(short4 r, int q) {
     const int hx = (r.z - r.x + 1) >> 1, hy = (r.w - r.y + 1) >> 1;
     const int mx = r.x + hx, my = r.y + hy;
@@ -1003,7 +1035,7 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
     u16* newPos = childPos + cap * 4;
     u8* nch = (u8*)(newPos + cap);
     u8* proc = nch + cap;
-    __shared__ u32 wsum[NT / 64];
+    __shared__ u32 wsum[2 * (NT / 64)];
     __shared__ int s_size, s_state, s_seqBase, s_cnt, s_ncand;
     const u32* cnts = candCnt + (size_t)frame * g.totalCells + L.cellBase;
     const u32* ents = candEnt + (size_t)frame * g.totalSlots + L.slotBase;
@@ -1075,10 +1107,11 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
             nd.cnt = s1[i]; nd.seq = i;
             tabA[size] = nd; newPos[i] = (u16)size; ++size;
         }
-        s_size = size; s_state = 0; s_seqBase = L.nIni; s_cnt = 0;
+        s_size = size; s_state = 0; s_seqBase = L.nIni; s_cnt = 0; s_ncand = 0;
     }
     __syncthreads();
     QT_FOR_KP({ (void)e; kn[ki] = newPos[nd]; })
+    for (int i = tid; i < L.nIni * 4; i += NT) qc[i] = 0;    // quadrant histograms of the first iteration (later ones: zeroed at the end of the previous)
     __syncthreads();
 
     QNode* A = tabA; QNode* B = tabB;
@@ -1086,10 +1119,7 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
         const int state = s_state, size = s_size;
         if (state == 2) break;
         if (iter > 4096) { if (tid == 0) atomicExch(err, 4); break; }
-        // (1) quadrant histograms of every splittable node
-        for (int i = tid; i < size * 4; i += NT) qc[i] = 0;
-        if (tid == 0) { s_cnt = 0; s_ncand = 0; }
-        __syncthreads();
+        // (1) quadrant histograms of every splittable node (qc, s_cnt, s_ncand were reset at the end of the previous iteration)
         QT_FOR_KP({ if (A[nd].cnt > 1) atomicAdd(&qc[nd * 4 + qt_quadrant(A[nd].r, e & 0xFFF, (e >> 12) & 0xFFF)], 1u); })
         __syncthreads();
         int totalCh = 0, newSize = 0;
@@ -1101,9 +1131,10 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
                 s1[i] = c; s2[i] = c > 0 ? 0 : 1;
             }
             __syncthreads();
-            totalCh = (int)block_scan_excl<NT>(s1, size, wsum, tid);
-            const int totalKeep = (int)block_scan_excl<NT>(s2, size, wsum, tid);
-            newSize = totalCh + totalKeep;
+            u32 totCh_, totKeep_;
+            block_scan2_excl<NT>(s1, size, s2, size, wsum, tid, &totCh_, &totKeep_);
+            totalCh = (int)totCh_;
+            newSize = totalCh + (int)totKeep_;
             for (int i = tid; i < size; i += NT) {
                 const int c = nch[i];
                 if (c > 0) {
@@ -1176,9 +1207,10 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
             __syncthreads();
             for (int i = tid; i < size; i += NT) s2[i] = proc[i] ? 0 : 1;
             __syncthreads();
-            totalCh = (int)block_scan_excl<NT>(s1, ncand, wsum, tid);
-            const int totalKeep = (int)block_scan_excl<NT>(s2, size, wsum, tid);
-            newSize = totalCh + totalKeep;
+            u32 totCh_, totKeep_;
+            block_scan2_excl<NT>(s1, ncand, s2, size, wsum, tid, &totCh_, &totKeep_);
+            totalCh = (int)totCh_;
+            newSize = totalCh + (int)totKeep_;
             for (int k = tid; k < P; k += NT) {
                 const int i = (int)(sortKey[n2 - 1 - k] & 0xFFFF);
                 const int c = nch[i];
@@ -1199,11 +1231,13 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
                 if (!proc[i]) { const int pos = totalCh + (int)s2[i]; B[pos] = A[i]; newPos[i] = (u16)pos; }
         }
         __syncthreads();
-        // (3) relabel the keypoints
+        // (3) relabel the keypoints; the next iteration's histograms start from zero
+        for (int i = tid; i < min(newSize, cap) * 4; i += NT) qc[i] = 0;
         QT_FOR_KP({ kn[ki] = proc[nd] ? childPos[nd * 4 + qt_quadrant(A[nd].r, e & 0xFFF, (e >> 12) & 0xFFF)] : newPos[nd]; })
         __syncthreads();
         if (tid == 0) {
             const int nToExpand = s_cnt;
+            s_cnt = 0; s_ncand = 0;
             s_seqBase += totalCh;
             s_size = newSize;
             if (newSize > cap) { atomicExch(err, 2); s_state = 2; }
