@@ -66,6 +66,7 @@ struct orbx {
     int rzTaskOff[12] = {}; bool rzStream[12] = {};
     int64_t algBytes = 0, fusedBytes = 0;
     size_t qtLds = 0, qt2Lds = 0;
+    int qtFuseD = 3;
     int maxIni = 1;                                            // most quadtree roots of any level
     int qt2Cap = 0, qt2Sort = 0;
     bool qtV1 = false, odV1 = false, serial = false, blurV2 = false, blurEarly = true;
@@ -395,9 +396,12 @@ static int build_geometry(orbx* o, int w, int h) {
         o->qtWide = o->qtWideForce >= 0 ? o->qtWideForce != 0 : maxN >= 512;   // many features per level: 1024-thread workgroups
         o->maxIni = 1;
         for (int l = 0; l < L; ++l) o->maxIni = std::max(o->maxIni, g.lv[l].nIni);
-        // + the fused first iterations' histograms (4 + 16 + 64 words per root), path table (64 halfwords per root) and per-node paths
+        // + the fused first iterations' histograms (4 + 16 + 64 (+ 256) words per root), path table and per-node paths.  A fourth fused
+        // iteration only happens when some level wants more than ~512 nodes (128 + 3 * 128 <= N), and 12 path bits hold 16 roots * 4^4 / 16
+        o->qtFuseD = (maxN >= 512 && o->maxIni <= 4) ? 4 : 3;
+        const size_t hw = o->qtFuseD == 4 ? 340 : 84, tw = o->qtFuseD == 4 ? 256 : 64;
         o->qt2Lds = (size_t)sc2 * 8 + (size_t)o->qt2Cap * (16 * 2 + 16 + 4 + 4 + 8 + 2 + 1 + 1) + (size_t)(o->maxCells + 1) * 4 + 64 +
-                    (size_t)o->maxIni * (84 * 4 + 64 * 2) + (size_t)o->qt2Cap * 4 + 8;
+                    (size_t)o->maxIni * (hw * 4 + tw * 2) + (size_t)o->qt2Cap * 4 + 8;
         if (o->qt2Lds > 160 * 1024 - 512) { set_err("quadtree for %d features/level needs %zu B of LDS (> 160 KiB)", maxN, o->qt2Lds); return ORBX_E_UNSUPPORTED; }
     }
     if (o->qtLds > 160 * 1024 - 512) { set_err("quadtree for %d features/level needs %zu B of LDS (> 160 KiB)", maxN, o->qtLds); return ORBX_E_UNSUPPORTED; }
@@ -862,10 +866,10 @@ static int extract_batch_async_impl(orbx_t* o, const uint8_t* const* imgs, int i
         Geom g2 = g; g2.nodeCap = o->qt2Cap; g2.sortCap = o->qt2Sort;
         if (o->qtWide)
             hipLaunchKernelGGL(k_quadtree2<1024>, dim3(nimg, g.nlevels), dim3(1024), o->qt2Lds, st, g2, o->dCandCnt, o->dCandEnt,
-                               o->dDense, o->dKpNode, o->dSel, o->dSelCnt, o->dErr, o->maxCells, o->maxIni);
+                               o->dDense, o->dKpNode, o->dSel, o->dSelCnt, o->dErr, o->maxCells, o->maxIni, o->qtFuseD);
         else
             hipLaunchKernelGGL(k_quadtree2<256>, dim3(nimg, g.nlevels), dim3(256), o->qt2Lds, st, g2, o->dCandCnt, o->dCandEnt,
-                               o->dDense, o->dKpNode, o->dSel, o->dSelCnt, o->dErr, o->maxCells, o->maxIni);
+                               o->dDense, o->dKpNode, o->dSel, o->dSelCnt, o->dErr, o->maxCells, o->maxIni, o->qtFuseD);
     }
     STAGE_EV(3, st);
     if (o->guardPending) {                                       // k_slots is the first writer of the result block (orbx_guard_results)

@@ -1016,7 +1016,7 @@ __device__ __forceinline__ short4 qt_child_rect(short4 r, int q) {
 // with 4000 features: the single workgroup per (frame, level) is the whole parallelism of this latency-bound kernel).
 template <int NT>
 __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict__ candCnt, const u32* __restrict__ candEnt,
-                                                   u32* dense, u16* kpNode, u32* selOut, u32* selCnt, int* err, int maxCells, int maxIni) {
+                                                   u32* dense, u16* kpNode, u32* selOut, u32* selCnt, int* err, int maxCells, int maxIni, int fuseD) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // grid = (frames, levels): consecutive workgroup ids go round-robin over the 8 XCDs, so the fastest-varying index must
     // be the frame -- with the level there and 8 levels, every level-0 (heaviest) workgroup would land on the same XCD
@@ -1035,12 +1035,13 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
     u16* newPos = childPos + cap * 4;
     u8* nch = (u8*)(newPos + cap);
     u8* proc = nch + cap;
-    // fused first iterations (below): quadrant histograms of the first three subdivision depths, indexed by path = ((root * 4 + q1) * 4 + q2) * 4 + q3
-    u32* H1 = (u32*)(smem + (((size_t)(proc + cap - smem) + 3) & ~(size_t)3));   // [maxIni * 4]
-    u32* H2 = H1 + maxIni * 4;                              // [maxIni * 16]
-    u32* H3 = H2 + maxIni * 16;                             // [maxIni * 64]
-    u16* T3 = (u16*)(H3 + maxIni * 64);                     // [maxIni * 64] depth-3 path -> node position
-    u16* pathA = T3 + maxIni * 64;                          // [cap] per node: path | depth << 12
+    // fused first iterations (below): quadrant histograms of the first fuseD (3 or 4) subdivision depths, indexed by the path
+    // ((root * 4 + q1) * 4 + q2) ...; the depth-d histogram [maxIni * 4^d] starts at word maxIni * (4^d - 4) / 3
+    u32* Hb = (u32*)(smem + (((size_t)(proc + cap - smem) + 3) & ~(size_t)3));
+#define QT_H(d) (Hb + maxIni * (((1 << (2 * (d))) - 4) / 3))
+    u32* HD = QT_H(fuseD);
+    u16* TD = (u16*)(HD + (maxIni << (2 * fuseD)));         // [maxIni * 4^fuseD] deepest path -> node position
+    u16* pathA = TD + (maxIni << (2 * fuseD));              // [cap] per node: path | depth << 12
     u16* pathB = pathA + cap;
     __shared__ u32 wsum[2 * (NT / 64)];
     __shared__ int s_size, s_state, s_seqBase, s_cnt, s_ncand;
@@ -1054,7 +1055,7 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
     const int nCells = L.nCells;
     for (int c = tid; c < nCells; c += NT) cellOff[c] = cnts[c];
     for (int i = tid; i < cap; i += NT) s1[i] = 0;
-    for (int i = tid; i < maxIni * 64; i += NT) H3[i] = 0;
+    for (int i = tid; i < (maxIni << (2 * fuseD)); i += NT) HD[i] = 0;
     __syncthreads();
     const int nk = (int)block_scan_excl<NT>(cellOff, nCells, wsum, tid);
     if (tid == 0) cellOff[nCells] = (u32)nk;
@@ -1086,13 +1087,14 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
                     const int x = (int)(e & 0xFFF), y = (int)((e >> 12) & 0xFFF);
                     const int root = (int)((float)x / L.hX);            // ORBextractor.cc:740
                     atomicAdd(&s1[root], 1u);
-                    // the candidate's path through the first three subdivisions, by the same rectangle arithmetic the iterations use
+                    // the candidate's path through the first fuseD subdivisions, by the same rectangle arithmetic the iterations use
                     short4 r = make_short4((short)(int)(L.hX * (float)root), 0, (short)(int)(L.hX * (float)(root + 1)), (short)L.qtH);
                     int path = root;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) { const int q = qt_quadrant(r, x, y); path = path * 4 + q; r = qt_child_rect(r, q); }
+                    for (int d = 0; d < 4; ++d)
+                        if (d < fuseD) { const int q = qt_quadrant(r, x, y); path = path * 4 + q; r = qt_child_rect(r, q); }
                     kn[i] = (u16)path;
-                    atomicAdd(&H3[path], 1u);
+                    atomicAdd(&HD[path], 1u);
                 }
             }
         }
@@ -1124,23 +1126,24 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
         }
         s_size = size; s_state = 0; s_seqBase = L.nIni; s_cnt = 0; s_ncand = 0;
     }
-    for (int i = tid; i < L.nIni * 16; i += NT) H2[i] = H3[4 * i] + H3[4 * i + 1] + H3[4 * i + 2] + H3[4 * i + 3];
-    __syncthreads();
-    for (int i = tid; i < L.nIni * 4; i += NT) H1[i] = H2[4 * i] + H2[4 * i + 1] + H2[4 * i + 2] + H2[4 * i + 3];
-    __syncthreads();
+    for (int d = fuseD - 1; d >= 1; --d) {                    // coarser histograms by summation
+        u32* Hc = QT_H(d); const u32* Hf = QT_H(d + 1);
+        for (int i = tid; i < (L.nIni << (2 * d)); i += NT) Hc[i] = Hf[4 * i] + Hf[4 * i + 1] + Hf[4 * i + 2] + Hf[4 * i + 3];
+        __syncthreads();
+    }
 
     QNode* A = tabA; QNode* B = tabB;
     u16* PA = pathA; u16* PB = pathB;
-    // ---- the first (up to three) iterations without touching the candidates.  While the list is far from N the loop at :779-895
+    // ---- the first (up to fuseD = three or four) iterations without touching the candidates.  While the list is far from N the loop at :779-895
     // splits EVERY node that holds more than one key, so after d such iterations the splittable nodes are exactly the depth-d
     // prefixes of the candidates' subdivision paths, and a node's four quadrant counts are the depth-(d+1) histogram entries under
-    // its path.  The paths and the depth-3 histogram were computed once in the gather pass; each of these iterations is then
+    // its path.  The paths and the deepest histogram were computed once in the gather pass; each of these iterations is then
     // node-level work only (same list surgery, same stop / phase-change tests as the general iteration below), and ONE relabel
     // pass at the end gives every candidate its node.  Two passes over the candidates per iteration is what the kernel's time was.
-    for (int d = 0; d < 3; ++d) {
+    for (int d = 0; d < fuseD; ++d) {
         const int state = s_state, size = s_size;
         if (state != 0) break;
-        const u32* Hn = d == 0 ? H1 : d == 1 ? H2 : H3;
+        const u32* Hn = QT_H(d + 1);
         for (int i = tid; i < size; i += NT) {
             int c = 0;
             if (A[i].cnt > 1) {
@@ -1192,14 +1195,14 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
         u16* tp_ = PA; PA = PB; PB = tp_;
         __syncthreads();
     }
-    {   // every candidate's node: depth-3 path -> position of the node whose path is a prefix of it
+    {   // every candidate's node: deepest path -> position of the node whose path is a prefix of it
         const int size = min(s_size, cap);
         for (int i = tid; i < size; i += NT) {
-            const int v = PA[i], sh = 2 * (3 - (v >> 12)), p = v & 0xFFF;
-            for (int j = p << sh; j < (p + 1) << sh; ++j) T3[j] = (u16)i;
+            const int v = PA[i], sh = 2 * (fuseD - (v >> 12)), p = v & 0xFFF;
+            for (int j = p << sh; j < (p + 1) << sh; ++j) TD[j] = (u16)i;
         }
         __syncthreads();
-        QT_FOR_KP({ (void)e; kn[ki] = T3[nd]; })
+        QT_FOR_KP({ (void)e; kn[ki] = TD[nd]; })
         for (int i = tid; i < size * 4; i += NT) qc[i] = 0;      // quadrant histograms of the next iteration (later ones: zeroed at the end of the previous)
         __syncthreads();
     }
@@ -1350,6 +1353,7 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
     }
     if (tid == 0) selCnt[frame * g.nlevels + level] = (u32)min(nsel, L.selCap);
 #undef QT_FOR_KP
+#undef QT_H
 }
 
 // ------------------------------------------------------------------------------------------------
