@@ -39,10 +39,13 @@ HBM_PEAK_GBS = 8000.0       # MI355X spec (MI355X_MICROARCH.md): 8.0 TB/s; 6.29 
 
 CONFIGS = {
     #        W     H     nF    frames/step  lapping       what
-    "c2": (752, 480, 1000, 512, (0, 1000), "configs[1]"),
-    "c5": (1920, 1080, 4000, 64, (0, 1000), "configs[4]"),
+    # frames/step is this build's choice (BASELINE.json fixes it only for configs[3]: 8 pairs): big enough that the ~85 us of kernel
+    # boundaries and graph-launch latency a step pays once are a few per cent of it (752x480: 512 frames 273 k frames/s, 1024 286 k,
+    # 2048 no further gain); 1024 frames hold 0.4 GB of images, 2.4 GB of pyramids and 8 x 62 MB of result blocks
+    "c2": (752, 480, 1000, 1024, (0, 1000), "configs[1]"),
+    "c5": (1920, 1080, 4000, 128, (0, 1000), "configs[4]"),
     "c4": (512, 512, 1500, 16, (0, 511), "configs[3]"),
-    "c3": (752, 480, 1200, 256, (0, 0), "configs[2]"),
+    "c3": (752, 480, 1200, 512, (0, 0), "configs[2]"),
 }
 
 
