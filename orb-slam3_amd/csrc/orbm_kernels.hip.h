@@ -593,31 +593,36 @@ __device__ __forceinline__ void stereo_body(const KpIn* __restrict__ kl, const u
         const u64 a[4] = {(u64)qlo.x | ((u64)qlo.y << 32), (u64)qlo.z | ((u64)qlo.w << 32),
                           (u64)qhi.x | ((u64)qhi.y << 32), (u64)qhi.z | ((u64)qhi.w << 32)};
         unsigned int best = 0xFFFFFFFFu;                                     // (dist << 16) | iR, strict < keeps the first
+        float bestx = 0.f;                                                   // x of this lane's best candidate
         int c0 = 0, c1 = nr;
         if (rowStart) { if (rowL >= 0 && rowL < nrows) { c0 = rowStart[rowL]; c1 = rowStart[rowL + 1]; } else c1 = 0; }
         for (int b0 = c0; b0 < c1; b0 += 64) {
             const int ci = b0 + lane;
             const int iR = rowStart ? (ci < c1 ? (int)rowIdx[ci] : nr) : ci;
             if (iR < nr) {
-                const KpIn kpR = kr[iR];
-                const float r = 2.0f * lv.sf(kpR.octave);
-                const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
-                if (rowL >= minr && rowL <= maxr && kpR.octave >= levelL - 1 && kpR.octave <= levelL + 1 &&
-                    kpR.x >= minU && kpR.x <= maxU) {
-                    const uint4* tp = (const uint4*)(dr + (size_t)iR * 32);
-                    const uint4 lo = tp[0], hi = tp[1];
+                // the candidate's descriptor is requested together with its keypoint, not after the gates (the kernel is bound by its
+                // chain of dependent memory round trips; a pair's right descriptors are 38 KB that stay in L2)
+                const float rx = kr[iR].x, ry = kr[iR].y;
+                const int ro = kr[iR].octave;
+                const uint4* tp = (const uint4*)(dr + (size_t)iR * 32);
+                const uint4 lo = tp[0], hi = tp[1];
+                const float r = 2.0f * lv.sf(ro);
+                const int maxr = (int)ceilf(ry + r), minr = (int)floorf(ry - r);
+                if (rowL >= minr && rowL <= maxr && ro >= levelL - 1 && ro <= levelL + 1 && rx >= minU && rx <= maxU) {
                     const int d = ham256(a, (u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
                                          (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32));
-                    best = min(best, ((unsigned)d << 16) | (unsigned)iR);
+                    const unsigned key = ((unsigned)d << 16) | (unsigned)iR;
+                    if (key < best) { best = key; bestx = rx; }
                 }
             }
         }
+        const unsigned mine = best;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
         const int bestDist = best == 0xFFFFFFFFu ? 100 : (int)(best >> 16);
         if (best != 0xFFFFFFFFu && bestDist < 100 && bestDist < 75) {        // < TH_HIGH to replace the init, < thOrbDist to go on
-            const int bestIdxR = (int)(best & 0xFFFFu);
-            const float uR0 = kr[bestIdxR].x;
+            // the winner's x comes from the lane that holds it (keys are unique: they carry the index), not from memory again
+            const float uR0 = __shfl(bestx, (int)__builtin_ctzll(__ballot(mine == best)));
             const float scaleFactor = lv.isf(levelL);
             const float scaleduL = roundf(kpL.x * scaleFactor), scaledvL = roundf(kpL.y * scaleFactor);
             const float scaleduR0 = roundf(uR0 * scaleFactor);
@@ -633,10 +638,17 @@ __device__ __forceinline__ void stereo_body(const KpIn* __restrict__ kl, const u
                 for (int k = 0; k < 11; ++k) sad[k] = 0;
                 for (int p = lane; p < 121; p += 64) {
                     const int dy = p / 11 - w, dx = p % 11 - w;
-                    const int vl = IL[(size_t)(cy + dy) * pl + cxl + dx];
+                    const unsigned vl = IL[(size_t)(cy + dy) * pl + cxl + dx];
                     const uint8_t* rr = IR + (size_t)(cy + dy) * pr + cxr + dx;
+                    // the 11 right pixels rr[-5..5] as three dword loads (global memory takes any alignment) instead of 11 byte loads;
+                    // v_sad_u8 on single-byte operands is |a - b| + accumulator in one instruction
+                    typedef unsigned int u32a __attribute__((aligned(1)));
+                    const unsigned w0 = *(const u32a*)(rr - 5), w1 = *(const u32a*)(rr - 1), w2 = *(const u32a*)(rr + 3);
 #pragma unroll
-                    for (int k = 0; k < 11; ++k) sad[k] += abs(vl - (int)rr[k - Lh]);
+                    for (int k = 0; k < 11; ++k) {
+                        const unsigned wk = k < 4 ? w0 : k < 8 ? w1 : w2;
+                        sad[k] = (int)__builtin_amdgcn_sad_u8(vl, (wk >> (8 * (k & 3))) & 0xFFu, (unsigned)sad[k]);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < 11; ++k)
