@@ -133,6 +133,7 @@ struct orbx {
     u8* hPinned = nullptr; size_t capPinned = 0; hipEvent_t evH2D = nullptr;   // pinned staging of host images
     u8* dIngest = nullptr; size_t capIngest = 0;               // grow-only scratch of the ingest entry points (pointer tables, staged colour images, CLAHE LUTs)
     std::vector<const u8*> upPtr; std::vector<int> upLap;      // what dL0Ptr / dLap currently hold
+    u8* hOne = nullptr; size_t capOne = 0;                    // pinned landing buffer of the single-frame call (k_fetch_one)
     u32 *dOvf = nullptr, *dOvfList = nullptr;                  // k_fast3 queue overflow list -> k_fast_fix
     size_t capOvfList = 0;
     int f3QcapForce = 0;                                       // ORBX_FAST_QCAP: test knob, forces a small queue
@@ -705,6 +706,7 @@ void orbx_destroy(orbx_t* o) {
     if (o->evGuard) (void)hipEventDestroy(o->evGuard);
     if (o->evH2D) (void)hipEventDestroy(o->evH2D);
     if (o->hPinned) (void)hipHostFree(o->hPinned);
+    if (o->hOne) (void)hipHostFree(o->hOne);
     if (o->dIngest) (void)hipFree(o->dIngest);
     for (auto& e : o->evLvl) if (e) (void)hipEventDestroy(e);
     if (o->stream) (void)hipStreamDestroy(o->stream);
@@ -1134,7 +1136,32 @@ int orbx_extract(orbx_t* o, const uint8_t* img, int w, int h, int stride, int la
     const int lap[2] = {lap0, lap1};
     int rc = orbx_extract_batch_async(o, &img, ORBX_HOST, 1, w, h, stride, lap);
     if (rc) return rc;
-    return orbx_result_fetch(o, 0, kps, desc, cap, mono_index);
+    // results: one packing kernel into pinned host memory and one synchronisation (k_fetch_one) instead of the general path's
+    // stream sync + error flag + counts + monos + keypoints + descriptors as separate synchronous copies
+    const int kc = o->g.kpCap;
+    const size_t descOff = (16 + (size_t)kc * 28 + 15) & ~(size_t)15;
+    const size_t need = descOff + (size_t)kc * 32;
+    if (need > o->capOne) {
+        if (o->hOne) (void)hipHostFree(o->hOne);
+        o->hOne = nullptr; o->capOne = 0;
+        HIPCHK(hipHostMalloc((void**)&o->hOne, need, hipHostMallocDefault));
+        o->capOne = need;
+    }
+    hipLaunchKernelGGL(k_fetch_one, dim3(8), dim3(256), 0, o->stream, o->dKps, o->dDesc, o->dN, o->dMono, o->dErr, 0, kc, (u32*)o->hOne, (int)(descOff / 4));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(o->stream));
+    { const int drc = dl_drain(o); if (drc) return drc; }
+    const u32* hd = (const u32*)o->hOne;
+    const int n = (int)hd[0], mono = (int)hd[1], e = (int)hd[2];
+    if (e) { set_err("device-side overflow flag %d", e); (void)hipMemset(o->dErr, 0, sizeof(int)); return ORBX_E_INTERNAL; }
+    o->hN.assign(1, n); o->hMono.assign(1, mono); o->countsValid = true;
+    if (n > cap) { set_err("%d keypoints exceed caller capacity %d", n, cap); return ORBX_E_CAPACITY; }
+    if (n > 0) {
+        if (kps) memcpy(kps, hd + 4, sizeof(KpOut) * (size_t)n);
+        if (desc) memcpy(desc, o->hOne + descOff, (size_t)32 * n);
+    }
+    if (mono_index) *mono_index = mono;
+    return n;
 }
 
 int orbx_level_size(const orbx_t* o, int level, int* w, int* h) {

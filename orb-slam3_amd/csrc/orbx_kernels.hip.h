@@ -2021,6 +2021,22 @@ __global__ __launch_bounds__(256) void k_copy_out(v4u_t* __restrict__ dst, const
         __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
+// k_fetch_one: the single-frame call's results in ONE piece -- header (n, mono, error flag, pad) + n keypoints + n descriptors, packed,
+// written straight into pinned host memory (five synchronous device-to-host copies of a few bytes to a few KB each cost the caller
+// ~0.1 ms; this costs one stream synchronisation).
+__global__ __launch_bounds__(256) void k_fetch_one(const KpOut* __restrict__ kps, const u8* __restrict__ desc, const int* __restrict__ nOut,
+                                                   const int* __restrict__ monoOut, const int* __restrict__ err, int frame, int kpCap, u32* out, int descWord) {
+    const int n = nOut[frame];
+    const int t = blockIdx.x * 256 + threadIdx.x, nt = gridDim.x * 256;
+    if (t == 0) { out[0] = (u32)n; out[1] = (u32)monoOut[frame]; out[2] = (u32)*err; out[3] = 0; }
+    const u32* ks = (const u32*)(kps + (size_t)frame * kpCap);
+    const uint4* ds = (const uint4*)(desc + (size_t)frame * kpCap * 32);
+    u32* ko = out + 4;
+    uint4* dout = (uint4*)(out + descWord);                      // fixed, 16-byte aligned offset behind room for kpCap keypoints
+    for (int i = t; i < n * 7; i += nt) ko[i] = ks[i];
+    for (int i = t; i < n * 2; i += nt) dout[i] = ds[i];
+}
+
 __global__ void k_stamp(unsigned long long* p) { *p = (unsigned long long)wall_clock64(); }
 
 __global__ __launch_bounds__(256) void k_gray(const u8* const* srcs, int w, int h, int sstride, int ch,
