@@ -1585,7 +1585,7 @@ int orbm_stereo_batch_async(orbm_t* m, void* extractor, int first_l, int first_r
     m->gridFirst = false;
     MHIPCHK(rec_time(m, m->e0));
     hipLaunchKernelGGL(k_stereo_rows, dim3(npairs), dim3(256), ldsRows, m->stream, (const KpIn*)kps, counts, cap, first_r, B, nrows, rowCap, rowStart, rowIdx, rowErr);
-    hipLaunchKernelGGL(k_stereo_batch, dim3((cap + 3) / 4, npairs), dim3(256), 0, m->stream, (const KpIn*)kps, desc, counts, cap, first_l, first_r, B, mb, mbf,
+    hipLaunchKernelGGL(k_stereo_batch, dim3((cap + 256 / ST_GS - 1) / (256 / ST_GS), npairs), dim3(256), 0, m->stream, (const KpIn*)kps, desc, counts, cap, first_l, first_r, B, mb, mbf,
                        uright, depth, sad, rowStart, rowIdx, nrows, rowCap);
     hipLaunchKernelGGL(k_stereo_cut, dim3(npairs), dim3(256), 0, m->stream, counts, cap, first_l, n2, sad, uright, depth, kept);
     MHIPCHK(rec_time(m, m->e1));

@@ -572,13 +572,15 @@ struct StereoLevels { const uint8_t* L[12]; const uint8_t* R[12]; int pitchL[12]
 // rowStart / rowIdx (optional): the reference's vRowIndices table (Frame.cc:1064-1083) as CSR over image rows -- the right
 // keypoints whose band [floor(y - r), ceil(y + r)] covers a row; with it a left keypoint only looks at the ~20 keypoints of its
 // row instead of all of them.  The winner is min (distance, iR) either way, so the order inside a row list does not matter.
-template <class LV>
+// GS = lanes per left keypoint (64: one per wave; 16: four per wave -- the kernel is bound by its chain of dependent memory round trips
+// at full occupancy, so the batched form quarters the number of waves that wait: 0.33 -> 0.21 ms per 256 pairs; 8 lanes: no further gain)
+template <int GS, class LV>
 __device__ __forceinline__ void stereo_body(const KpIn* __restrict__ kl, const uint8_t* __restrict__ dl, int nl,
                                             const KpIn* __restrict__ kr, const uint8_t* __restrict__ dr, int nr,
                                             const LV& lv, float mb, float mbf, float* __restrict__ uright,
                                             float* __restrict__ depth, int* __restrict__ bestSad, int iL,
                                             const int* __restrict__ rowStart = nullptr, const unsigned short* __restrict__ rowIdx = nullptr, int nrows = 0) {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & (GS - 1), grp = (threadIdx.x & 63) / GS;
     const KpIn kpL = kl[iL];
     const int levelL = kpL.octave;
     const float vL = kpL.y, uL = kpL.x;
@@ -596,7 +598,7 @@ __device__ __forceinline__ void stereo_body(const KpIn* __restrict__ kl, const u
         float bestx = 0.f;                                                   // x of this lane's best candidate
         int c0 = 0, c1 = nr;
         if (rowStart) { if (rowL >= 0 && rowL < nrows) { c0 = rowStart[rowL]; c1 = rowStart[rowL + 1]; } else c1 = 0; }
-        for (int b0 = c0; b0 < c1; b0 += 64) {
+        for (int b0 = c0; b0 < c1; b0 += GS) {
             const int ci = b0 + lane;
             const int iR = rowStart ? (ci < c1 ? (int)rowIdx[ci] : nr) : ci;
             if (iR < nr) {
@@ -618,11 +620,13 @@ __device__ __forceinline__ void stereo_body(const KpIn* __restrict__ kl, const u
         }
         const unsigned mine = best;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+        for (int o = GS / 2; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
         const int bestDist = best == 0xFFFFFFFFu ? 100 : (int)(best >> 16);
         if (best != 0xFFFFFFFFu && bestDist < 100 && bestDist < 75) {        // < TH_HIGH to replace the init, < thOrbDist to go on
             // the winner's x comes from the lane that holds it (keys are unique: they carry the index), not from memory again
-            const float uR0 = __shfl(bestx, (int)__builtin_ctzll(__ballot(mine == best)));
+            unsigned long long who = __ballot(mine == best);
+            if (GS < 64) who = (who >> (GS * grp)) & ((1ull << GS) - 1ull);   // this keypoint's lanes
+            const float uR0 = __shfl(bestx, (int)__builtin_ctzll(who) + GS * grp);
             const float scaleFactor = lv.isf(levelL);
             const float scaleduL = roundf(kpL.x * scaleFactor), scaledvL = roundf(kpL.y * scaleFactor);
             const float scaleduR0 = roundf(uR0 * scaleFactor);
@@ -636,7 +640,7 @@ __device__ __forceinline__ void stereo_body(const KpIn* __restrict__ kl, const u
                 int sad[11];
 #pragma unroll
                 for (int k = 0; k < 11; ++k) sad[k] = 0;
-                for (int p = lane; p < 121; p += 64) {
+                for (int p = lane; p < 121; p += GS) {
                     const int dy = p / 11 - w, dx = p % 11 - w;
                     const unsigned vl = IL[(size_t)(cy + dy) * pl + cxl + dx];
                     const uint8_t* rr = IR + (size_t)(cy + dy) * pr + cxr + dx;
@@ -653,7 +657,7 @@ __device__ __forceinline__ void stereo_body(const KpIn* __restrict__ kl, const u
 #pragma unroll
                 for (int k = 0; k < 11; ++k)
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) sad[k] += __shfl_xor(sad[k], o);
+                    for (int o = GS / 2; o > 0; o >>= 1) sad[k] += __shfl_xor(sad[k], o);
                 int bestD = 0x7FFFFFFF, bestinc = 0;
 #pragma unroll
                 for (int k = 0; k < 11; ++k) {
@@ -699,7 +703,7 @@ __global__ __launch_bounds__(256) void k_stereo(const KpIn* __restrict__ kl, con
     const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (iL >= nl) return;
     const StereoLevelsView v{lv};
-    stereo_body(kl, dl, nl, kr, dr, nr, v, mb, mbf, uright, depth, bestSad, iL);
+    stereo_body<64>(kl, dl, nl, kr, dr, nr, v, mb, mbf, uright, depth, bestSad, iL);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -774,12 +778,15 @@ __global__ __launch_bounds__(256) void k_stereo_batch(const KpIn* __restrict__ k
                                                       const int* __restrict__ rowStart, const unsigned short* __restrict__ rowIdx, int nrows, int rowCap) {
     const int pair = blockIdx.y, fl = first_l + pair, fr = first_r + pair;
     const int nl = min(counts[fl], cap), nr = min(counts[fr], cap);
-    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+#ifndef ST_GS
+#define ST_GS 16
+#endif
+    const int iL = blockIdx.x * (256 / ST_GS) + (threadIdx.x / ST_GS);   // 64 / ST_GS left keypoints per wave (ST_GS lanes each)
     if (iL >= nl) return;
     const StereoBatchView v{B, fl, fr};
     const size_t o = (size_t)pair * cap;
-    if (nr == 0) { if ((threadIdx.x & 63) == 0) { uright[o + iL] = -1.0f; depth[o + iL] = -1.0f; bestSad[o + iL] = -1; } return; }
-    stereo_body(kps + (size_t)fl * cap, desc + (size_t)fl * cap * 32, nl, kps + (size_t)fr * cap, desc + (size_t)fr * cap * 32, nr, v, mb, mbf,
+    if (nr == 0) { if ((threadIdx.x & (ST_GS - 1)) == 0) { uright[o + iL] = -1.0f; depth[o + iL] = -1.0f; bestSad[o + iL] = -1; } return; }
+    stereo_body<ST_GS>(kps + (size_t)fl * cap, desc + (size_t)fl * cap * 32, nl, kps + (size_t)fr * cap, desc + (size_t)fr * cap * 32, nr, v, mb, mbf,
                 uright + o, depth + o, bestSad + o, iL, rowStart ? rowStart + (size_t)pair * (nrows + 1) : nullptr,
                 rowIdx ? rowIdx + (size_t)pair * rowCap : nullptr, nrows);
 }
