@@ -14,6 +14,8 @@ CASES = [
     (752, 480, 1000, 0, (0, 0), "constant"),
     (640, 480, 1000, 5, (100, 400), "textured"),
     (421, 307, 500, 6, (0, 0), "textured"),          # odd sizes, ragged last cells
+    (752, 480, 5000, 9, (0, 1000), "textured"),      # the initialisation extractor (5 * nFeatures, Tracking.cc:1113): > 512 nodes per level -> four fused quadtree iterations
+    (2400, 420, 1500, 11, (0, 0), "textured"),       # wide frame: six quadtree roots per level
 ]
 
 
