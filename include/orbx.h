@@ -48,7 +48,10 @@ int orbx_max_keypoints(const orbx_t*);
 
 /* replaces ORBextractor::operator() (ORBextractor.cc:1534-1659) for one image.
  * img: host pointer, row stride in bytes.  kps/desc: host buffers with room for `cap` entries
- * (desc is cap x 32 bytes).  Returns n >= 0 keypoints, writes *mono_index (the reference's return value). */
+ * (desc is cap x 32 bytes).  Returns n >= 0 keypoints, writes *mono_index (the reference's return value).
+ * Synchronous.  With per-stage timing off (orbx_set_stage_timing(o, 0), what the C++ facade does) the third and later calls with
+ * an unchanged image size replay the whole frame -- staging copy, both streams' kernels, result packing -- as one captured graph;
+ * ORBX_ONE_GRAPH=0 in the environment keeps every call on the eager path. */
 int orbx_extract(orbx_t*, const uint8_t* img, int w, int h, int stride, int lap0, int lap1,
                  orbx_kp_t* kps, uint8_t* desc, int cap, int* mono_index);
 

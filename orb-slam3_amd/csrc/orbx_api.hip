@@ -109,8 +109,11 @@ struct orbx {
     // and its own timing events (recorded as external event nodes, so a replay refreshes them)
     struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int nimg = 0, block = 0; long launches = 0; };
     unsigned long long* dStamps = nullptr; int wallClockKHz = 0;   // k_stamp slots [kSlots][4]
-    static const int kSlots = 8;
-    GraphSlot gs[kSlots];
+    static const int kSlots = 8;                               // public graph slots (orbx_capture_begin)
+    static const int kAllSlots = kSlots + 1;                   // + the single-frame call's own graph (orbx_extract)
+    GraphSlot gs[kAllSlots];
+    int oneW = 0, oneH = 0, oneEager = 0;                      // geometry the single-frame graph was captured for; eager calls seen since
+    bool oneOff = false;                                       // capture failed once (or ORBX_ONE_GRAPH=0): stay eager
     int capSlot = -1;                                          // >= 0 while the streams are being captured
     bool capFailed = false;                                    // an enqueue failed inside the open capture
     bool graphMode = false;                                    // the most recent batch came from a graph replay
@@ -176,6 +179,7 @@ static int build_geometry(orbx* o, int w, int h) {
         if (G.graph) (void)hipGraphDestroy(G.graph);
         G.exec = nullptr; G.graph = nullptr; G.launches = 0; G.nimg = 0;
     }
+    o->oneW = o->oneH = 0; o->oneEager = 0;
     o->upPtr.clear(); o->upLap.clear();
     for (auto& v : o->attach) v.clear();                       // the block layout is about to change
     Geom& g = o->g;
@@ -624,6 +628,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     o->blurTiled = !o->blurV2 && !o->odV1 && getenv("ORBX_BLUR_ROWMAJOR") == nullptr;
     o->dlKernel = getenv("ORBX_DL_KERNEL") != nullptr;          // A/B: results-to-host copy by k_copy_out instead of the copy engine
     if (const char* e = getenv("ORBX_DL_GRID")) o->dlGrid = std::max(1, atoi(e));
+    if (const char* e = getenv("ORBX_ONE_GRAPH")) o->oneOff = atoi(e) == 0;   // A/B: single-frame calls stay eager
     o->serial = getenv("ORBX_SERIAL") != nullptr;            // A/B switch: simple per-cell reference kernel
     o->scaleFactor = scale_factor;                              // double member initialised from float (ORBextractor.h:96)
     const int L = nlevels;
@@ -652,7 +657,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
         if (rc == ORBX_OK && hipStreamCreateWithFlags(&o->stream3, hipStreamNonBlocking) != hipSuccess) { rc = ORBX_E_HIP; set_err("copy stream creation failed"); }
         for (auto& e : o->evBatchDone) if (rc == ORBX_OK && hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
         for (auto& e : o->evDepc) if (rc == ORBX_OK && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rc = ORBX_E_HIP; set_err("hipEventCreate failed"); }
-        if (rc == ORBX_OK && (hipMalloc((void**)&o->dStamps, sizeof(unsigned long long) * orbx::kSlots * 4) != hipSuccess ||
+        if (rc == ORBX_OK && (hipMalloc((void**)&o->dStamps, sizeof(unsigned long long) * orbx::kAllSlots * 4) != hipSuccess ||
                               hipDeviceGetAttribute(&o->wallClockKHz, hipDeviceAttributeWallClockRate, device_id) != hipSuccess || o->wallClockKHz <= 0)) { rc = ORBX_E_HIP; set_err("time stamp setup failed"); }
         if (rc) break;
         const size_t B = max_batch;
@@ -761,6 +766,7 @@ static int extract_batch_async_impl(orbx_t* o, const uint8_t* const* imgs, int i
         if (need > o->capPinned) {
             if (o->hPinned) (void)hipHostFree(o->hPinned);
             o->hPinned = nullptr; o->capPinned = 0;
+            o->oneW = o->oneH = 0;                                // the single-frame graph copies out of the old buffer
             HIPCHK(hipHostMalloc((void**)&o->hPinned, need, hipHostMallocDefault));
             o->capPinned = need;
         }
@@ -1133,28 +1139,27 @@ int orbx_result_fetch_all(orbx_t* o, orbx_kp_t* kps, uint8_t* desc, int cap_per_
     return B;
 }
 
-int orbx_extract(orbx_t* o, const uint8_t* img, int w, int h, int stride, int lap0, int lap1,
-                 orbx_kp_t* kps, uint8_t* desc, int cap, int* mono_index) {
-    if (!o) return ORBX_E_INVALID;
-    if (!img || w <= 0 || h <= 0) return ORBX_E_EMPTY;
-    const int lap[2] = {lap0, lap1};
-    int rc = orbx_extract_batch_async(o, &img, ORBX_HOST, 1, w, h, stride, lap);
-    if (rc) return rc;
-    // results: one packing kernel into pinned host memory and one synchronisation (k_fetch_one) instead of the general path's
-    // stream sync + error flag + counts + monos + keypoints + descriptors as separate synchronous copies
+// ---- the single-frame call.  A frame's ~17 kernels, event records and waits cost the calling thread ~0.15 ms to enqueue -- as long
+// as the GPU needs to run them -- so from the third call with the same geometry on (and per-stage timing off) the whole sequence
+// [image staging buffer -> HBM, lapping area -> HBM, extraction on both streams, k_fetch_one] is replayed as ONE hipGraphLaunch;
+// per call the host only copies the image into the pinned staging buffer and reads the packed results back out of pinned memory.
+static size_t one_desc_off(int kc) { return (16 + (size_t)kc * 28 + 15) & ~(size_t)15; }
+
+static int one_landing(orbx* o) {                                // pinned landing buffer [header | kps | desc | lapping area]
     const int kc = o->g.kpCap;
-    const size_t descOff = (16 + (size_t)kc * 28 + 15) & ~(size_t)15;
-    const size_t need = descOff + (size_t)kc * 32;
+    const size_t need = one_desc_off(kc) + (size_t)kc * 32 + 16;
     if (need > o->capOne) {
         if (o->hOne) (void)hipHostFree(o->hOne);
         o->hOne = nullptr; o->capOne = 0;
+        o->oneW = o->oneH = 0;                                   // a captured graph would hold the old pointer
         HIPCHK(hipHostMalloc((void**)&o->hOne, need, hipHostMallocDefault));
         o->capOne = need;
     }
-    hipLaunchKernelGGL(k_fetch_one, dim3(8), dim3(256), 0, o->stream, o->dKps, o->dDesc, o->dN, o->dMono, o->dErr, 0, kc, (u32*)o->hOne, (int)(descOff / 4));
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(o->stream));
-    { const int drc = dl_drain(o); if (drc) return drc; }
+    return ORBX_OK;
+}
+
+static int one_results(orbx* o, orbx_kp_t* kps, uint8_t* desc, int cap, int* mono_index) {
+    const int kc = o->g.kpCap;
     const u32* hd = (const u32*)o->hOne;
     const int n = (int)hd[0], mono = (int)hd[1], e = (int)hd[2];
     if (e) { set_err("device-side overflow flag %d", e); (void)hipMemset(o->dErr, 0, sizeof(int)); return ORBX_E_INTERNAL; }
@@ -1162,9 +1167,102 @@ int orbx_extract(orbx_t* o, const uint8_t* img, int w, int h, int stride, int la
     if (n > cap) { set_err("%d keypoints exceed caller capacity %d", n, cap); return ORBX_E_CAPACITY; }
     if (n > 0) {
         if (kps) memcpy(kps, hd + 4, sizeof(KpOut) * (size_t)n);
-        if (desc) memcpy(desc, o->hOne + descOff, (size_t)32 * n);
+        if (desc) memcpy(desc, o->hOne + one_desc_off(kc), (size_t)32 * n);
     }
     if (mono_index) *mono_index = mono;
+    return n;
+}
+
+static void one_launch_fetch(orbx* o) {
+    const int kc = o->g.kpCap;
+    hipLaunchKernelGGL(k_fetch_one, dim3(8), dim3(256), 0, o->stream, o->dKps, o->dDesc, o->dN, o->dMono, o->dErr, 0, kc, (u32*)o->hOne,
+                       (int)(one_desc_off(kc) / 4));
+}
+
+// capture the sequence for the current geometry into the private slot; on any failure the handle stays on the eager path for good
+static void one_capture(orbx* o, int w, int h) {
+    const int slot = orbx::kSlots;
+    orbx::GraphSlot& G = o->gs[slot];
+    if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
+    if (G.graph) { (void)hipGraphDestroy(G.graph); G.graph = nullptr; }
+    G.launches = 0; G.nimg = 0;
+    o->oneW = o->oneH = 0;
+    if (hipStreamSynchronize(o->stream) != hipSuccess || hipStreamSynchronize(o->stream2) != hipSuccess || dl_drain(o)) { o->oneOff = true; return; }
+    const int kc = o->g.kpCap;
+    int* lapPinned = (int*)(o->hOne + one_desc_off(kc) + (size_t)kc * 32);
+    const size_t imgBytes = (size_t)o->l0pitch * h;
+    if (hipStreamBeginCapture(o->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); o->oneOff = true; return; }
+    o->capSlot = slot; o->capFailed = false;
+    bool ok = hipMemcpyAsync(o->dL0, o->hPinned, imgBytes, hipMemcpyHostToDevice, o->stream) == hipSuccess &&
+              hipMemcpyAsync(o->dLap, lapPinned, 2 * sizeof(int), hipMemcpyHostToDevice, o->stream) == hipSuccess;
+    if (ok) {
+        const uint8_t* dimg = o->dL0;
+        const int lap[2] = {lapPinned[0], lapPinned[1]};
+        o->upLap.assign(lap, lap + 2);                           // the captured copy above uploads them on every replay
+        ok = orbx_extract_batch_async(o, &dimg, ORBX_DEVICE, 1, w, h, o->l0pitch, lap) == ORBX_OK;
+    }
+    if (ok) { one_launch_fetch(o); ok = hipGetLastError() == hipSuccess; }
+    o->capSlot = -1;
+    hipGraph_t graph = nullptr;
+    const hipError_t e2 = hipStreamEndCapture(o->stream, &graph);
+    if (!ok || e2 != hipSuccess || !graph || o->capFailed || G.nimg != 1 ||
+        hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        G.exec = nullptr; G.nimg = 0; o->oneOff = true;
+        return;
+    }
+    G.graph = graph;
+    o->oneW = w; o->oneH = h;
+}
+
+int orbx_extract(orbx_t* o, const uint8_t* img, int w, int h, int stride, int lap0, int lap1,
+                 orbx_kp_t* kps, uint8_t* desc, int cap, int* mono_index) {
+    if (!o) return ORBX_E_INVALID;
+    if (!img || w <= 0 || h <= 0) return ORBX_E_EMPTY;
+    const int lap[2] = {lap0, lap1};
+    HIPCHK(hipSetDevice(o->device));
+    const bool graphOk = !o->oneOff && !o->stageTiming && !o->serial && o->capSlot < 0;
+    if (graphOk && o->gs[orbx::kSlots].exec && o->oneW == w && o->oneH == h && o->curW == w && o->curH == h && stride >= w) {
+        // ---- replay
+        orbx::GraphSlot& G = o->gs[orbx::kSlots];
+        { const int rc = dl_wait_block(o, G.block); if (rc) return rc; }
+        const int kc = o->g.kpCap;
+        if (o->evH2D) HIPCHK(hipEventSynchronize(o->evH2D));     // an asynchronous batch of host images may still be leaving the staging buffer
+        u8* p = o->hPinned;
+        if (stride == o->l0pitch) memcpy(p, img, (size_t)stride * h);
+        else for (int y = 0; y < h; ++y) memcpy(p + (size_t)y * o->l0pitch, img + (size_t)y * stride, (size_t)w);
+        int* lapPinned = (int*)(o->hOne + one_desc_off(kc) + (size_t)kc * 32);
+        lapPinned[0] = lap0; lapPinned[1] = lap1;
+        HIPCHK(hipGraphLaunch(G.exec, o->stream));
+        ++G.launches;
+        { const int rc = orbx_set_result_block(o, G.block); if (rc) return rc; }
+        o->hL0Ptr[0] = o->dL0; o->lastL0Pitch = o->l0pitch;
+        o->hLap[0] = lap0; o->hLap[1] = lap1; o->upLap.assign(lap, lap + 2);
+        o->lastBatch = 1; o->countsValid = false; o->timed = true; o->graphMode = true;
+        HIPCHK(hipStreamSynchronize(o->stream));
+        return one_results(o, kps, desc, cap, mono_index);
+    }
+    int rc = orbx_extract_batch_async(o, &img, ORBX_HOST, 1, w, h, stride, lap);
+    if (rc) return rc;
+    // results: one packing kernel into pinned host memory and one synchronisation (k_fetch_one) instead of the general path's
+    // stream sync + error flag + counts + monos + keypoints + descriptors as separate synchronous copies
+    rc = one_landing(o);
+    if (rc) return rc;
+    one_launch_fetch(o);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(o->stream));
+    { const int drc = dl_drain(o); if (drc) return drc; }
+    const int n = one_results(o, kps, desc, cap, mono_index);
+    if (n >= 0 && graphOk) {
+        if (o->oneW == w && o->oneH == h) o->oneEager = 0;
+        else if (++o->oneEager >= 2) {                           // same geometry twice in a row on the eager path: worth a graph
+            int* lapPinned = (int*)(o->hOne + one_desc_off(o->g.kpCap) + (size_t)o->g.kpCap * 32);
+            lapPinned[0] = lap0; lapPinned[1] = lap1;
+            one_capture(o, w, h);
+            o->oneEager = 0;
+        }
+    }
     return n;
 }
 
@@ -1299,10 +1397,10 @@ int orbx_mean_timings(orbx_t* o, float* ms8, int* nsamples) {
     int n = 0;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (o->graphMode) {                                      // replays refresh their slot's own stamps: the latest replay of every slot
-        unsigned long long st[orbx::kSlots * 4];
+        unsigned long long st[orbx::kAllSlots * 4];
         HIPCHK(hipMemcpy(st, o->dStamps, sizeof st, hipMemcpyDeviceToHost));
         const double msPerTick = 1.0 / (double)o->wallClockKHz;
-        for (int k = 0; k < orbx::kSlots; ++k) {
+        for (int k = 0; k < orbx::kAllSlots; ++k) {
             const orbx::GraphSlot& G = o->gs[k];
             if (!G.exec || G.launches < 1 || G.nimg < 1) continue;
             const unsigned long long* t = st + 4 * k;

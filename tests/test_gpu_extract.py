@@ -359,3 +359,30 @@ def test_graph_replay_and_result_blocks_bit_exact(pkg, oracle, synth):
     ex(synth.gen_image(400, 300, 1))
     assert L.orbx_graph_launch(ex.h, 0) < 0
     ex.close(); mt.close()
+
+
+def test_single_frame_graph_replay(pkg, oracle, synth):
+    """orbx_extract replays the whole single-frame sequence as one graph from the third call with the same geometry on (per-stage
+    timing off): images, lapping areas and sizes change between calls; every result must equal the oracle's."""
+    ex = pkg.ORBextractor(800, max_size=(752, 480), max_batch=1)
+    assert ex.L.orbx_set_stage_timing(ex.h, 0) == 0
+    ref = oracle.Extractor(800)
+    plan = [(752, 480, 21, (0, 0)), (752, 480, 22, (0, 1000)), (752, 480, 23, (100, 400)), (752, 480, 21, (0, 0)), (752, 480, 24, (300, 310)),
+            (640, 360, 25, (0, 0)), (640, 360, 26, (0, 700)), (640, 360, 27, (5, 50)), (640, 360, 25, (0, 0)),       # geometry switch: new graph
+            (752, 480, 22, (0, 1000)), (752, 480, 28, (0, 0)), (752, 480, 29, (0, 0))]
+    for w, h, seed, lap in plan:
+        img = synth.gen_image(w, h, seed)
+        n_ref, kps_ref, desc_ref, mono_ref = ref(img, lap)
+        mono, kps, desc = ex(img, lap)
+        assert len(kps) == n_ref and mono == mono_ref, (w, h, seed, lap)
+        assert kps.tobytes() == kps_ref.tobytes() and np.array_equal(desc, desc_ref), (w, h, seed, lap)
+    # a non-contiguous caller stride and the batch API in between must not confuse the replay path
+    big = np.zeros((480, 800), np.uint8); big[:, :752] = synth.gen_image(752, 480, 30)
+    view = big[:, :752]
+    kps = np.zeros(ex.cap, pkg.KP_DTYPE); desc = np.zeros((ex.cap, 32), np.uint8)
+    import ctypes as C
+    mono = C.c_int32(0)
+    n = ex.L.orbx_extract(ex.h, big.ctypes.data_as(C.c_void_p), 752, 480, 800, 0, 0, kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), ex.cap, C.byref(mono))
+    n_ref, kps_ref, desc_ref, mono_ref = ref(np.ascontiguousarray(view), (0, 0))
+    assert n == n_ref and kps[:n].tobytes() == kps_ref.tobytes() and np.array_equal(desc[:n], desc_ref)
+    ex.close()

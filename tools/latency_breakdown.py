@@ -45,3 +45,5 @@ print("SearchByProjection(Frame,points)  resident frame        : %.3f ms" % med(
 print("resident frame creation (upload + device grid build)   : %.3f ms" % med(lambda: pkg.ResidentFrame(m, view).close(), 50))
 print("grid build (host arrays)                               : %.3f ms" % med(lambda: pkg.FrameView(kr, dr, 752, 480, backend=m), 50))
 print("one extraction (host image in, host results out)       : %.3f ms" % med(lambda: exl(l, (0, 0)), 50))
+exl.L.orbx_set_stage_timing(exl.h, 0)                        # what the C++ facade does: no per-stage events -> single-graph replay
+print("  ... per-stage timing off (graph replay)               : %.3f ms" % med(lambda: exl(l, (0, 0)), 50))
