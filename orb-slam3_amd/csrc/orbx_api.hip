@@ -13,6 +13,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <deque>
+#include <chrono>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -114,6 +115,7 @@ struct orbx {
     GraphSlot gs[kAllSlots];
     int oneW = 0, oneH = 0, oneEager = 0;                      // geometry the single-frame graph was captured for; eager calls seen since
     bool oneOff = false;                                       // capture failed once (or ORBX_ONE_GRAPH=0): stay eager
+    double oneEagerUs = 0;                                     // enqueue-to-synchronised time of the last eager single-frame call
     int capSlot = -1;                                          // >= 0 while the streams are being captured
     bool capFailed = false;                                    // an enqueue failed inside the open capture
     bool graphMode = false;                                    // the most recent batch came from a graph replay
@@ -1207,13 +1209,29 @@ static void one_capture(orbx* o, int w, int h) {
     o->capSlot = -1;
     hipGraph_t graph = nullptr;
     const hipError_t e2 = hipStreamEndCapture(o->stream, &graph);
-    if (!ok || e2 != hipSuccess || !graph || o->capFailed || G.nimg != 1 ||
-        hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    if (!ok || e2 != hipSuccess || !graph || o->capFailed || G.nimg != 1) {
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
         G.exec = nullptr; G.nimg = 0; o->oneOff = true;
         return;
     }
+    // How hipGraph places a small graph's nodes differs from one instantiation to the next (a 16-frame step: 0.24 or 0.32 ms), so the
+    // replay is timed against the eager call it is meant to beat -- on the frame still in the staging buffer, results land in the
+    // landing buffer and are simply overwritten -- and re-instantiated, at most twice, if it does not.
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        if (hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); G.exec = nullptr; break; }
+        double best = 1e30;
+        bool ran = true;
+        for (int r = 0; r < 3 && ran; ++r) {
+            const auto t0 = std::chrono::steady_clock::now();
+            ran = hipGraphLaunch(G.exec, o->stream) == hipSuccess && hipStreamSynchronize(o->stream) == hipSuccess;
+            best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        }
+        if (ran && (o->oneEagerUs <= 0 || best < 0.85 * o->oneEagerUs)) break;   // (the eager figure includes ~25 us of staging memcpy the replay here does not)
+        (void)hipGraphExecDestroy(G.exec); G.exec = nullptr;
+        (void)hipGetLastError();
+    }
+    if (!G.exec) { (void)hipGraphDestroy(graph); G.nimg = 0; o->oneOff = true; return; }
     G.graph = graph;
     o->oneW = w; o->oneH = h;
 }
@@ -1245,6 +1263,7 @@ int orbx_extract(orbx_t* o, const uint8_t* img, int w, int h, int stride, int la
         HIPCHK(hipStreamSynchronize(o->stream));
         return one_results(o, kps, desc, cap, mono_index);
     }
+    const auto tEager = std::chrono::steady_clock::now();
     int rc = orbx_extract_batch_async(o, &img, ORBX_HOST, 1, w, h, stride, lap);
     if (rc) return rc;
     // results: one packing kernel into pinned host memory and one synchronisation (k_fetch_one) instead of the general path's
@@ -1254,6 +1273,7 @@ int orbx_extract(orbx_t* o, const uint8_t* img, int w, int h, int stride, int la
     one_launch_fetch(o);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(o->stream));
+    o->oneEagerUs = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tEager).count();
     { const int drc = dl_drain(o); if (drc) return drc; }
     const int n = one_results(o, kps, desc, cap, mono_index);
     if (n >= 0 && graphOk) {
