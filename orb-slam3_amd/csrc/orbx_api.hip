@@ -13,6 +13,9 @@
 #include <cstring>
 #include <condition_variable>
 #include <deque>
+#include <dlfcn.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 #include <chrono>
 #include <mutex>
 #include <thread>
@@ -540,8 +543,52 @@ static inline hipEvent_t dep_ev(orbx* o, int i) { return o->capSlot < 0 ? o->ev[
 #define STAGE_EV(i, stream) do { if (o->stageTiming && o->capSlot < 0) HIPCHK(hipEventRecord(o->ev[i], stream)); } while (0)
 
 // ---- helper thread of the results-to-host copies (see struct orbx)
+// ---- The results-to-host copy goes through hsa_amd_memory_async_copy (a DMA engine).  hipMemcpyAsync is executed by this runtime as a
+// copy KERNEL, which beside the saturated extraction moves ~19 GB/s -- less than the stereo step produces (21 GB/s): C3 213 k -> 231 k
+// frames/s with the DMA engine, results identical.  The HSA runtime is the one HIP already loaded (dlopen by soname, no link
+// dependency); if it cannot be had, or a destination is not pinned memory it knows, the copy falls back to hipMemcpyAsync.
+// ORBX_DL_HSA=0: A/B switch.
+struct HsaCopy {
+    bool ok = false;
+    hsa_status_t (*init)() = nullptr;
+    hsa_status_t (*ptrinfo)(const void*, hsa_amd_pointer_info_t*, void* (*)(size_t), uint32_t*, hsa_agent_t**) = nullptr;
+    hsa_status_t (*sigcreate)(hsa_signal_value_t, uint32_t, const hsa_agent_t*, hsa_signal_t*) = nullptr;
+    void (*sigstore)(hsa_signal_t, hsa_signal_value_t) = nullptr;
+    hsa_signal_value_t (*sigwait)(hsa_signal_t, hsa_signal_condition_t, hsa_signal_value_t, uint64_t, hsa_wait_state_t) = nullptr;
+    hsa_status_t (*copy)(void*, hsa_agent_t, const void*, hsa_agent_t, size_t, uint32_t, const hsa_signal_t*, hsa_signal_t) = nullptr;
+    hsa_signal_t sig{};
+    bool load() {
+        void* h = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return false;
+        init = (decltype(init))dlsym(h, "hsa_init"); ptrinfo = (decltype(ptrinfo))dlsym(h, "hsa_amd_pointer_info");
+        sigcreate = (decltype(sigcreate))dlsym(h, "hsa_signal_create"); sigstore = (decltype(sigstore))dlsym(h, "hsa_signal_store_relaxed");
+        sigwait = (decltype(sigwait))dlsym(h, "hsa_signal_wait_scacquire"); copy = (decltype(copy))dlsym(h, "hsa_amd_memory_async_copy");
+        if (!init || !ptrinfo || !sigcreate || !sigstore || !sigwait || !copy) return false;
+        if (init() != HSA_STATUS_SUCCESS || sigcreate(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return false;
+        return ok = true;
+    }
+    // n pieces, all device -> pinned host; returns false if any piece cannot go this way (nothing copied then is waited for anyway)
+    bool run(void* const* dst, const void* const* src, const size_t* bytes, int n) {
+        sigstore(sig, n);
+        int issued = 0;
+        bool good = true;
+        for (int i = 0; i < n && good; ++i) {
+            hsa_amd_pointer_info_t ps{}, pd{}; ps.size = sizeof ps; pd.size = sizeof pd;
+            good = ptrinfo(src[i], &ps, nullptr, nullptr, nullptr) == HSA_STATUS_SUCCESS && ptrinfo(dst[i], &pd, nullptr, nullptr, nullptr) == HSA_STATUS_SUCCESS &&
+                   ps.type != HSA_EXT_POINTER_TYPE_UNKNOWN && pd.type != HSA_EXT_POINTER_TYPE_UNKNOWN &&
+                   copy(dst[i], pd.agentOwner, src[i], ps.agentOwner, bytes[i], 0, nullptr, sig) == HSA_STATUS_SUCCESS;
+            if (good) ++issued;
+        }
+        if (issued < n) sigstore(sig, issued);   // (pieces not issued never signal)
+        if (issued) while (sigwait(sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) != 0) {}
+        return good;
+    }
+};
+
 static void dl_worker(orbx* o) {
     (void)hipSetDevice(o->device);
+    HsaCopy hsa;
+    bool useHsa = !(getenv("ORBX_DL_HSA") && atoi(getenv("ORBX_DL_HSA")) == 0) && !o->dlKernel && hsa.load();
     for (;;) {
         orbx::DlReq r;
         {
@@ -551,7 +598,16 @@ static void dl_worker(orbx* o) {
             r = o->dlQueue.front();
         }
         hipError_t e = hipEventSynchronize(o->evBatchDone[r.block]);      // host-side wait: the copy below has no device-side dependency
-        if (e == hipSuccess) {
+        bool done = false;
+        if (e == hipSuccess && useHsa && o->attach[r.block].size() < 31) {
+            void* dst[32]; const void* src[32]; size_t nb[32];
+            int n = 0;
+            dst[n] = r.host; src[n] = o->rb[r.block].base; nb[n] = o->blockBytes; ++n;
+            for (const orbx::Attach& a : o->attach[r.block]) { dst[n] = (u8*)r.host + a.hostOff; src[n] = a.dev; nb[n] = a.bytes; ++n; }
+            done = hsa.run(dst, src, nb, n);
+            if (!done) useHsa = false;                           // e.g. a pageable destination: the runtime's own copy handles it (all pieces again)
+        }
+        if (e == hipSuccess && !done) {
             if (o->dlKernel) {
                 const size_t n16 = o->blockBytes / 16;               // blockBytes is a multiple of 256
                 const unsigned grid = (unsigned)std::min<size_t>(o->dlGrid, (n16 + 255) / 256);
