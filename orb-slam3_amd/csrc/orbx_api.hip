@@ -1299,7 +1299,9 @@ int orbx_extract(orbx_t* o, const uint8_t* img, int w, int h, int stride, int la
     const int lap[2] = {lap0, lap1};
     HIPCHK(hipSetDevice(o->device));
     const bool graphOk = !o->oneOff && !o->stageTiming && !o->serial && o->capSlot < 0;
-    if (graphOk && o->gs[orbx::kSlots].exec && o->oneW == w && o->oneH == h && o->curW == w && o->curH == h && stride >= w) {
+    // (the graph's kernels read the device-side image-pointer table as it was at capture: a batch call in between may have rewritten it)
+    const bool tableOk = o->upPtr.size() == 1 && o->upPtr[0] == o->dL0;
+    if (graphOk && tableOk && o->gs[orbx::kSlots].exec && o->oneW == w && o->oneH == h && o->curW == w && o->curH == h && stride >= w) {
         // ---- replay
         orbx::GraphSlot& G = o->gs[orbx::kSlots];
         { const int rc = dl_wait_block(o, G.block); if (rc) return rc; }

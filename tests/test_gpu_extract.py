@@ -376,6 +376,18 @@ def test_single_frame_graph_replay(pkg, oracle, synth):
         mono, kps, desc = ex(img, lap)
         assert len(kps) == n_ref and mono == mono_ref, (w, h, seed, lap)
         assert kps.tobytes() == kps_ref.tobytes() and np.array_equal(desc, desc_ref), (w, h, seed, lap)
+    # a batch call with device-resident images rewrites the handle's image-pointer table: the next single-frame call must notice
+    dev = pkg.DeviceBuffer(752 * 480)
+    other = synth.gen_image(752, 480, 31)
+    dev.upload(np.ascontiguousarray(other))
+    import ctypes as C
+    ptrs = (C.c_void_p * 1)(int(dev.ptr))
+    ex.enqueue_device(ptrs, 752, 480, 752, [0, 0]); ex.sync()
+    img = synth.gen_image(752, 480, 28)
+    n_ref, kps_ref, desc_ref, mono_ref = ref(img, (0, 0))
+    for _ in range(4):
+        mono, kps, desc = ex(img, (0, 0))
+        assert len(kps) == n_ref and kps.tobytes() == kps_ref.tobytes() and np.array_equal(desc, desc_ref)
     # a non-contiguous caller stride and the batch API in between must not confuse the replay path
     big = np.zeros((480, 800), np.uint8); big[:, :752] = synth.gen_image(752, 480, 30)
     view = big[:, :752]
