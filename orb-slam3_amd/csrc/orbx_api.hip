@@ -1298,7 +1298,7 @@ int orbx_extract(orbx_t* o, const uint8_t* img, int w, int h, int stride, int la
     if (!img || w <= 0 || h <= 0) return ORBX_E_EMPTY;
     const int lap[2] = {lap0, lap1};
     HIPCHK(hipSetDevice(o->device));
-    const bool graphOk = !o->oneOff && !o->stageTiming && !o->serial && o->capSlot < 0;
+    const bool graphOk = !o->oneOff && !o->stageTiming && !o->serial && o->capSlot < 0 && !o->guardPending;   // (a pending orbx_guard_results wait is eager-path business)
     // (the graph's kernels read the device-side image-pointer table as it was at capture: a batch call in between may have rewritten it)
     const bool tableOk = o->upPtr.size() == 1 && o->upPtr[0] == o->dL0;
     if (graphOk && tableOk && o->gs[orbx::kSlots].exec && o->oneW == w && o->oneH == h && o->curW == w && o->curH == h && stride >= w) {
