@@ -79,6 +79,10 @@ int orbx_result_fetch_all(orbx_t*, orbx_kp_t* kps, uint8_t* desc, int cap_per_im
 /* mvImagePyramid back-door (include/ORBextractor.h:83; used by Frame::ComputeStereoMatches, Frame.cc:1168) */
 int orbx_level_size(const orbx_t*, int level, int* w, int* h);
 int orbx_level_image(orbx_t*, int frame, int level, int blurred, uint8_t* dst, int dst_stride);
+/* all levels of one frame of the last batch at once: dst[l] / dst_stride[l] per level (dst[l] = NULL skips a level).  One copy of the
+ * frame's pyramid slab out of HBM plus host row copies; level 0 of a host-image call comes from the staging buffer.  This is what
+ * the facade fills mvImagePyramid (include/ORBextractor.h:83) with after operator(). */
+int orbx_pyramid_fetch(orbx_t*, int frame, uint8_t* const* dst, const int* dst_stride);
 /* GetScaleFactors & co (include/ORBextractor.h:61-79) */
 void orbx_scale_tables(const orbx_t*, float* sf, float* inv_sf, float* sig2, float* inv_sig2);
 int orbx_features_per_level(const orbx_t*, int* nfeat);

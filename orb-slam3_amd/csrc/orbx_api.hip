@@ -141,6 +141,7 @@ struct orbx {
     u8* hPinned = nullptr; size_t capPinned = 0; hipEvent_t evH2D = nullptr;   // pinned staging of host images
     u8* dIngest = nullptr; size_t capIngest = 0;               // grow-only scratch of the ingest entry points (pointer tables, staged colour images, CLAHE LUTs)
     std::vector<const u8*> upPtr; std::vector<int> upLap;      // what dL0Ptr / dLap currently hold
+    u8* hPyr = nullptr; size_t capPyrHost = 0;                // pinned landing buffer of orbx_pyramid_fetch
     u8* hOne = nullptr; size_t capOne = 0;                    // pinned landing buffer of the single-frame call (k_fetch_one)
     u32 *dOvf = nullptr, *dOvfList = nullptr;                  // k_fast3 queue overflow list -> k_fast_fix
     size_t capOvfList = 0;
@@ -770,6 +771,7 @@ void orbx_destroy(orbx_t* o) {
     if (o->evH2D) (void)hipEventDestroy(o->evH2D);
     if (o->hPinned) (void)hipHostFree(o->hPinned);
     if (o->hOne) (void)hipHostFree(o->hOne);
+    if (o->hPyr) (void)hipHostFree(o->hPyr);
     if (o->dIngest) (void)hipFree(o->dIngest);
     for (auto& e : o->evLvl) if (e) (void)hipEventDestroy(e);
     if (o->stream) (void)hipStreamDestroy(o->stream);
@@ -1376,6 +1378,42 @@ int orbx_level_image(orbx_t* o, int frame, int level, int blurred, uint8_t* dst,
     }
     const u8* base = blurred ? o->dBlur + (size_t)frame * o->g.blrFrameBytes + D.boff : o->dPyr + (size_t)frame * o->g.pyrFrameBytes + D.off;
     HIPCHK(hipMemcpy2D(dst, dst_stride, base, D.pitch, D.w, D.h, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+// every level of one frame of the last batch in one go (the facade's mvImagePyramid, ORBextractor.h:83): levels 1.. leave HBM as ONE
+// copy of the frame's pyramid slab into pinned memory, level 0 of a host image comes back out of the staging buffer it was uploaded
+// from -- instead of one synchronous 2-D copy per level (8 x ~35 us, more than the extraction of a 752x480 frame itself).
+int orbx_pyramid_fetch(orbx_t* o, int frame, uint8_t* const* dst, const int* dst_stride) {
+    if (!o || !dst || !dst_stride || frame < 0 || frame >= o->lastBatch || !o->curW) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    const Geom& g = o->g;
+    if (g.pyrFrameBytes > o->capPyrHost) {
+        if (o->hPyr) (void)hipHostFree(o->hPyr);
+        o->hPyr = nullptr; o->capPyrHost = 0;
+        HIPCHK(hipHostMalloc((void**)&o->hPyr, g.pyrFrameBytes, hipHostMallocDefault));
+        o->capPyrHost = g.pyrFrameBytes;
+    }
+    if (g.nlevels > 1) HIPCHK(hipMemcpyAsync(o->hPyr, o->dPyr + (size_t)frame * g.pyrFrameBytes, g.pyrFrameBytes, hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipStreamSynchronize(o->stream));                     // (also: everything the batch enqueued has run)
+    for (int l = 0; l < g.nlevels; ++l) {
+        const LevelDesc& D = g.lv[l];
+        if (!dst[l]) continue;
+        if (l == 0) {
+            const u8* src = o->hL0Ptr[frame];
+            const bool staged = o->hPinned && src >= o->dL0 && src < o->dL0 + o->capL0 && (size_t)(src - o->dL0) + (size_t)o->l0pitch * D.h <= o->capPinned;
+            if (staged) {                                        // the host copy of what was uploaded is still in the staging buffer
+                const u8* hp = o->hPinned + (src - o->dL0);
+                for (int y = 0; y < D.h; ++y) memcpy(dst[0] + (size_t)y * dst_stride[0], hp + (size_t)y * o->l0pitch, (size_t)D.w);
+            } else {
+                const int rc = orbx_level_image(o, frame, 0, 0, dst[0], dst_stride[0]);
+                if (rc) return rc;
+            }
+            continue;
+        }
+        const u8* hp = o->hPyr + D.off;
+        for (int y = 0; y < D.h; ++y) memcpy(dst[l] + (size_t)y * dst_stride[l], hp + (size_t)y * D.pitch, (size_t)D.w);
+    }
     return ORBX_OK;
 }
 

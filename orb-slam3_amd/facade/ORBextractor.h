@@ -65,20 +65,23 @@ public:
     std::vector<float> inline GetInverseScaleSigmaSquares() { return table(3); }
 
     // include/ORBextractor.h:83 -- Frame::ComputeStereoMatches slices these on the host (Frame.cc:1168,1194), so by default
-    // every operator() copies the levels back (about 1.4x the image, one copy per level).  An integration whose stereo
+    // every operator() copies the levels back (about 1.4x the image; one copy out of HBM for all of them, orbx_pyramid_fetch).  An integration whose stereo
     // association runs on the device (orbm_stereo_matches reads the levels in HBM) switches that off with
     // KeepPyramidOnDevice(true) and calls FetchImagePyramid() only if it ever needs the pixels.
     std::vector<cv::Mat> mvImagePyramid;
     void KeepPyramidOnDevice(bool on) { hostPyramid = !on; }
     void FetchImagePyramid() {
         if (!h || !pyramidStale) return;
+        std::vector<uint8_t*> dst(nlevels);
+        std::vector<int> stride(nlevels);
         for (int l = 0; l < nlevels; ++l) {
             int w = 0, hh = 0;
             orbx_level_size(h, l, &w, &hh);
             mvImagePyramid[l].create(hh, w, CV_8U);
-            if (orbx_level_image(h, 0, l, 0, mvImagePyramid[l].data, (int)mvImagePyramid[l].step) < 0)
-                throw std::runtime_error(std::string("orbx_level_image: ") + orbx_last_error());
+            dst[l] = mvImagePyramid[l].data; stride[l] = (int)mvImagePyramid[l].step;
         }
+        if (orbx_pyramid_fetch(h, 0, dst.data(), stride.data()) < 0)      // one copy out of HBM for all levels
+            throw std::runtime_error(std::string("orbx_pyramid_fetch: ") + orbx_last_error());
         pyramidStale = false;
     }
     orbx_t* handle() { return h; }          // for orbm_stereo_matches

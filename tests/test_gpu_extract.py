@@ -398,3 +398,22 @@ def test_single_frame_graph_replay(pkg, oracle, synth):
     n_ref, kps_ref, desc_ref, mono_ref = ref(np.ascontiguousarray(view), (0, 0))
     assert n == n_ref and kps[:n].tobytes() == kps_ref.tobytes() and np.array_equal(desc[:n], desc_ref)
     ex.close()
+
+
+def test_pyramid_fetch_equals_per_level_fetch(pkg, synth):
+    """orbx_pyramid_fetch (all levels with one copy; level 0 from the staging buffer) against orbx_level_image level by level,
+    for a host image and for a frame of a device-resident batch."""
+    img = synth.gen_image(641, 479, 41)
+    ex = pkg.ORBextractor(500, max_size=(641, 479), max_batch=2)
+    ex(img, (0, 0))
+    for lv, got in enumerate(ex.pyramid(0)):
+        assert np.array_equal(got, ex.level_image(lv)), lv
+    assert np.array_equal(ex.pyramid(0)[0], img)
+    imgs = [synth.gen_image(641, 479, 42), synth.gen_image(641, 479, 43)]
+    ex.extract_batch(imgs, [(0, 0), (0, 0)])
+    for f in range(2):
+        pyr = ex.pyramid(f)
+        assert np.array_equal(pyr[0], imgs[f])
+        for lv in range(1, 8):
+            assert np.array_equal(pyr[lv], ex.level_image(lv, frame=f)), (f, lv)
+    ex.close()

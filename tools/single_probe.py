@@ -23,3 +23,12 @@ for _ in range(200):
     te.append(t1 - t0); ts.append(t2 - t0)
     t0 = time.perf_counter(); full(); tf.append(time.perf_counter() - t0)
 print("enqueue only %.3f ms; enqueue + sync %.3f ms; orbx_extract (with results on the host) %.3f ms" % tuple(1e3 * float(np.median(x)) for x in (te, ts, tf)))
+# the facade's default also brings the pyramid back to the host (mvImagePyramid): one call for all levels vs one per level
+def pyr_all(): ex.pyramid(0)
+def pyr_each():
+    for l in range(8): ex.level_image(l)
+ta, tb = [], []
+for _ in range(100):
+    full(); t0 = time.perf_counter(); pyr_all(); ta.append(time.perf_counter() - t0)
+    full(); t0 = time.perf_counter(); pyr_each(); tb.append(time.perf_counter() - t0)
+print("pyramid to host: orbx_pyramid_fetch %.3f ms; eight orbx_level_image calls %.3f ms" % (1e3 * float(np.median(ta)), 1e3 * float(np.median(tb))))
