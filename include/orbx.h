@@ -83,6 +83,10 @@ int orbx_level_image(orbx_t*, int frame, int level, int blurred, uint8_t* dst, i
  * frame's pyramid slab out of HBM plus host row copies; level 0 of a host-image call comes from the staging buffer.  This is what
  * the facade fills mvImagePyramid (include/ORBextractor.h:83) with after operator(). */
 int orbx_pyramid_fetch(orbx_t*, int frame, uint8_t* const* dst, const int* dst_stride);
+/* the same without host copies: ptr[l] / pitch[l] point into pinned memory of the handle (level 0: the staging buffer of a host
+ * image, NULL for a device-resident frame), valid until the next extraction or pyramid call on this handle -- the lifetime the
+ * reference's mvImagePyramid has (the extractor overwrites it on every call). */
+int orbx_pyramid_map(orbx_t*, int frame, const uint8_t** ptr, int* pitch);
 /* GetScaleFactors & co (include/ORBextractor.h:61-79) */
 void orbx_scale_tables(const orbx_t*, float* sf, float* inv_sf, float* sig2, float* inv_sig2);
 int orbx_features_per_level(const orbx_t*, int* nfeat);

@@ -26,7 +26,7 @@ EXPORTS = [
     # include/orbx.h
     "orbx_create", "orbx_destroy", "orbx_last_error", "orbx_max_keypoints", "orbx_extract", "orbx_extract_batch",
     "orbx_extract_batch_async", "orbx_sync", "orbx_result_device", "orbx_result_fetch", "orbx_result_fetch_all", "orbx_level_size",
-    "orbx_level_image", "orbx_pyramid_fetch", "orbx_scale_tables", "orbx_features_per_level", "orbx_level_candidates",
+    "orbx_level_image", "orbx_pyramid_fetch", "orbx_pyramid_map", "orbx_scale_tables", "orbx_features_per_level", "orbx_level_candidates",
     "orbx_level_selected", "orbx_last_timings", "orbx_set_stage_timing", "orbx_mean_timings", "orbx_stream_wait_results", "orbx_stream_wait_other", "orbx_guard_results", "orbx_gray_from_color", "orbx_remap_linear", "orbx_clahe", "orbx_algorithmic_bytes", "orbx_blur_in_pass", "orbx_stream", "orbx_dev_alloc",
     "orbx_dev_free", "orbx_memcpy_h2d", "orbx_memcpy_d2h", "orbx_device_count",
     "orbx_capture_begin", "orbx_capture_end", "orbx_graph_launch", "orbx_result_download_async", "orbx_result_block_layout", "orbx_block_attach", "orbx_block_detach_all", "orbx_download_sync",
@@ -377,6 +377,21 @@ class ORBextractor:
         self.L.orbx_pyramid_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _chk(self.L.orbx_pyramid_fetch(self.h, frame, ptrs, strides), "pyramid_fetch")
         return outs
+
+    def pyramid_views(self, frame=0):
+        """zero-copy views of every level in the handle's pinned memory (orbx_pyramid_map); valid until the next call on the handle."""
+        n = self.GetLevels()
+        ptrs = (C.c_void_p * n)(); pitch = (C.c_int * n)()
+        self.L.orbx_pyramid_map.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _chk(self.L.orbx_pyramid_map(self.h, frame, ptrs, pitch), "pyramid_map")
+        out = []
+        for l in range(n):
+            w, h = self.level_size(l)
+            if not ptrs[l]:
+                out.append(None); continue
+            buf = (C.c_uint8 * (pitch[l] * h)).from_address(ptrs[l])
+            out.append(np.frombuffer(buf, np.uint8).reshape(h, pitch[l])[:, :w])
+        return out
 
     def level_candidates(self, level, frame=0):
         n = _chk(self.L.orbx_level_candidates(self.h, frame, level, None, 0), "level_candidates")

@@ -1429,6 +1429,29 @@ int orbx_pyramid_fetch(orbx_t* o, int frame, uint8_t* const* dst, const int* dst
     return ORBX_OK;
 }
 
+// zero-copy form of orbx_pyramid_fetch: the frame's pyramid slab lands in the handle's pinned buffer and the caller gets a pointer
+// and a row pitch per level (level 0: the staging buffer the image was uploaded from; NULL when the frame was device-resident).
+// The memory belongs to the handle and is overwritten by the next extraction / fetch -- exactly the lifetime of the reference's
+// mvImagePyramid, which the extractor overwrites on every call (ORBextractor.cc:1672).
+int orbx_pyramid_map(orbx_t* o, int frame, const uint8_t** ptr, int* pitch) {
+    if (!o || !ptr || !pitch || frame < 0 || frame >= o->lastBatch || !o->curW) return ORBX_E_INVALID;
+    HIPCHK(hipSetDevice(o->device));
+    const Geom& g = o->g;
+    if (g.pyrFrameBytes > o->capPyrHost) {
+        if (o->hPyr) (void)hipHostFree(o->hPyr);
+        o->hPyr = nullptr; o->capPyrHost = 0;
+        HIPCHK(hipHostMalloc((void**)&o->hPyr, g.pyrFrameBytes, hipHostMallocDefault));
+        o->capPyrHost = g.pyrFrameBytes;
+    }
+    if (g.nlevels > 1) HIPCHK(hipMemcpyAsync(o->hPyr, o->dPyr + (size_t)frame * g.pyrFrameBytes, g.pyrFrameBytes, hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipStreamSynchronize(o->stream));
+    const u8* src = o->hL0Ptr[frame];
+    const bool staged = o->hPinned && src >= o->dL0 && src < o->dL0 + o->capL0 && (size_t)(src - o->dL0) + (size_t)o->l0pitch * g.lv[0].h <= o->capPinned;
+    ptr[0] = staged ? o->hPinned + (src - o->dL0) : nullptr; pitch[0] = staged ? o->l0pitch : 0;
+    for (int l = 1; l < g.nlevels; ++l) { ptr[l] = o->hPyr + g.lv[l].off; pitch[l] = g.lv[l].pitch; }
+    return ORBX_OK;
+}
+
 void orbx_scale_tables(const orbx_t* o, float* sf, float* inv_sf, float* sig2, float* inv_sig2) {
     for (int i = 0; i < o->nlevels; ++i) {
         if (sf) sf[i] = o->sf[i];

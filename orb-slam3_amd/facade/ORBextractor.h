@@ -65,23 +65,29 @@ public:
     std::vector<float> inline GetInverseScaleSigmaSquares() { return table(3); }
 
     // include/ORBextractor.h:83 -- Frame::ComputeStereoMatches slices these on the host (Frame.cc:1168,1194), so by default
-    // every operator() copies the levels back (about 1.4x the image; one copy out of HBM for all of them, orbx_pyramid_fetch).  An integration whose stereo
+    // every operator() brings the levels back (one copy of the pyramid slab out of HBM into pinned memory, orbx_pyramid_map; the Mats are headers over it).  An integration whose stereo
     // association runs on the device (orbm_stereo_matches reads the levels in HBM) switches that off with
     // KeepPyramidOnDevice(true) and calls FetchImagePyramid() only if it ever needs the pixels.
     std::vector<cv::Mat> mvImagePyramid;
     void KeepPyramidOnDevice(bool on) { hostPyramid = !on; }
     void FetchImagePyramid() {
         if (!h || !pyramidStale) return;
-        std::vector<uint8_t*> dst(nlevels);
-        std::vector<int> stride(nlevels);
+        // zero-copy: the levels are cv::Mat headers over the handle's pinned memory (one copy out of HBM for all of them), valid until
+        // the next operator() -- the reference's extractor overwrites mvImagePyramid on every call too
+        std::vector<const uint8_t*> ptr(nlevels);
+        std::vector<int> pitch(nlevels);
+        if (orbx_pyramid_map(h, 0, ptr.data(), pitch.data()) < 0)
+            throw std::runtime_error(std::string("orbx_pyramid_map: ") + orbx_last_error());
         for (int l = 0; l < nlevels; ++l) {
             int w = 0, hh = 0;
             orbx_level_size(h, l, &w, &hh);
-            mvImagePyramid[l].create(hh, w, CV_8U);
-            dst[l] = mvImagePyramid[l].data; stride[l] = (int)mvImagePyramid[l].step;
+            if (ptr[l]) mvImagePyramid[l] = cv::Mat(hh, w, CV_8U, (void*)ptr[l], (size_t)pitch[l]);
+            else {                                               // (device-resident level 0: copy)
+                mvImagePyramid[l].create(hh, w, CV_8U);
+                if (orbx_level_image(h, 0, l, 0, mvImagePyramid[l].data, (int)mvImagePyramid[l].step) < 0)
+                    throw std::runtime_error(std::string("orbx_level_image: ") + orbx_last_error());
+            }
         }
-        if (orbx_pyramid_fetch(h, 0, dst.data(), stride.data()) < 0)      // one copy out of HBM for all levels
-            throw std::runtime_error(std::string("orbx_pyramid_fetch: ") + orbx_last_error());
         pyramidStale = false;
     }
     orbx_t* handle() { return h; }          // for orbm_stereo_matches

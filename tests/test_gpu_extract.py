@@ -417,3 +417,14 @@ def test_pyramid_fetch_equals_per_level_fetch(pkg, synth):
         for lv in range(1, 8):
             assert np.array_equal(pyr[lv], ex.level_image(lv, frame=f)), (f, lv)
     ex.close()
+
+
+def test_pyramid_map_views(pkg, synth):
+    img = synth.gen_image(641, 479, 44)
+    ex = pkg.ORBextractor(500, max_size=(641, 479), max_batch=1)
+    ex(img, (0, 0))
+    views = ex.pyramid_views(0)
+    assert np.array_equal(views[0], img)
+    for lv in range(1, 8):
+        assert np.array_equal(np.array(views[lv]), ex.level_image(lv)), lv
+    ex.close()
