@@ -55,6 +55,8 @@ struct MockMapPoint {                                           // include/MapPo
 static cv::Mat eye4() { return cv::Mat::eye(4, 4, CV_32F); }
 
 struct MockFrame {                                              // include/Frame.h
+    static inline unsigned long nNextId = 0;                    // Frame.h: static long unsigned int nNextId; long unsigned int mnId
+    unsigned long mnId = nNextId++;                             // (identifies the frame's immutable feature data: the facade keeps such frames in HBM)
     int N = 0, Nleft = -1;
     std::vector<cv::KeyPoint> mvKeys, mvKeysUn, mvKeysRight;
     cv::Mat mDescriptors;
@@ -229,6 +231,13 @@ int main(int argc, char** argv) {
         std::printf("facade: M3 SearchByProjection(Frame,MapPoints) %d matches (flattened call: %d)\n", got, want);
         CHECK(got == want && got > n / 3, 35);
         for (int k = 0; k < n; ++k) CHECK((match[k] >= 0 ? &pts[match[k]] : nullptr) == F.mvpMapPoints[k], 36);
+        // the same Frame again (now resident in HBM: only the queries travel) and a copy of it (same mnId, as mLastFrame = Frame(mCurrentFrame))
+        for (auto& q : F.mvpMapPoints) q = nullptr;
+        CHECK(mm.SearchByProjection(F, vp, 3.f, true, 5.5f) == want, 37);
+        for (int k = 0; k < n; ++k) CHECK((match[k] >= 0 ? &pts[match[k]] : nullptr) == F.mvpMapPoints[k], 38);
+        MockFrame F3 = F;
+        for (auto& q : F3.mvpMapPoints) q = nullptr;
+        CHECK(mm.SearchByProjection(F3, vp, 3.f, true, 5.5f) == want, 39);
         for (auto& p : pts) p.mbTrackInView = false;
     }
     {   // ---- M5 SearchByProjection(Frame, KeyFrame, sAlreadyFound, th, ORBdist): relocalisation
