@@ -912,7 +912,8 @@ static int extract_batch_async_impl(orbx_t* o, const uint8_t* const* imgs, int i
         // (already satisfied -- the last FAST group waited for the last level -- but NOT removable: without this edge hipGraph places
         // the blur branch and the FAST branch of the captured step differently and the two no longer overlap: step 1.83 -> 2.07 ms)
         HIPCHK(hipStreamWaitEvent(st, dep_ev(o, 8), 0));         // later stages read every level
-        hipLaunchKernelGGL(k_fast_fix, dim3(512), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dCells, o->dCandCnt, o->dCandEnt,
+        // (grid sized to the batch: a single frame's launch of 512 workgroups that find nothing to do costs 18 us, of 8 workgroups 8 us)
+        hipLaunchKernelGGL(k_fast_fix, dim3((unsigned)std::min(512, std::max(8, 4 * nimg))), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dCells, o->dCandCnt, o->dCandEnt,
                            o->dErr, o->dOvf, o->dOvfList);
     }
     HIPCHK(rec_ev(o, 2, st, true));
