@@ -559,12 +559,15 @@ struct HsaCopy {
     hsa_signal_value_t (*sigwait)(hsa_signal_t, hsa_signal_condition_t, hsa_signal_value_t, uint64_t, hsa_wait_state_t) = nullptr;
     hsa_status_t (*copy)(void*, hsa_agent_t, const void*, hsa_agent_t, size_t, uint32_t, const hsa_signal_t*, hsa_signal_t) = nullptr;
     hsa_signal_t sig{};
+    hsa_status_t (*sigdestroy)(hsa_signal_t) = nullptr;
+    ~HsaCopy() { if (ok && sigdestroy) (void)sigdestroy(sig); }
     bool load() {
         void* h = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!h) return false;
         init = (decltype(init))dlsym(h, "hsa_init"); ptrinfo = (decltype(ptrinfo))dlsym(h, "hsa_amd_pointer_info");
         sigcreate = (decltype(sigcreate))dlsym(h, "hsa_signal_create"); sigstore = (decltype(sigstore))dlsym(h, "hsa_signal_store_relaxed");
         sigwait = (decltype(sigwait))dlsym(h, "hsa_signal_wait_scacquire"); copy = (decltype(copy))dlsym(h, "hsa_amd_memory_async_copy");
+        sigdestroy = (decltype(sigdestroy))dlsym(h, "hsa_signal_destroy");
         if (!init || !ptrinfo || !sigcreate || !sigstore || !sigwait || !copy) return false;
         if (init() != HSA_STATUS_SUCCESS || sigcreate(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return false;
         return ok = true;
