@@ -36,6 +36,8 @@ struct orbm {
     uint8_t* arDev = nullptr; uint8_t* arPin = nullptr;
     size_t arCap = 0, arOff = 0, arUp = 0, arOutLo = (size_t)-1, arOutHi = 0;   // bump offset; [0, arUp) staged uploads; small outputs in [arOutLo, arOutHi)
     uint8_t* scr = nullptr; size_t scrCap = 0;                 // grow-only device scratch of the batched (enqueue-only) entry points
+    std::vector<uint8_t*> scrOld;                              // superseded scratch blocks: graphs captured earlier still hold their addresses, so they live as long as the handle
+    int* hStatus = nullptr;                                    // pinned, device-visible status word of the enqueue-only entry points (capacity overflows); read by orbm_sync
 };
 
 // scratch of the enqueue-only entry points: grows outside a capture only (an allocation cannot be recorded into a graph)
@@ -43,11 +45,12 @@ static uint8_t* batch_scratch(orbm* m, size_t bytes) {
     if (bytes <= m->scrCap && m->scr) return m->scr;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(m->stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) return nullptr;
-    (void)hipStreamSynchronize(m->stream);
-    if (m->scr) (void)hipFree(m->scr);
-    m->scr = nullptr; m->scrCap = 0;
-    if (hipMalloc((void**)&m->scr, bytes) != hipSuccess) return nullptr;
-    m->scrCap = bytes;
+    // grow by ADDING: a step graph captured through orbx_capture_begin keeps the old block's address in its kernel nodes, and
+    // a later eager call with more pairs must not turn that graph's next replay into a use-after-free
+    uint8_t* nb = nullptr;
+    if (hipMalloc((void**)&nb, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (m->scr) m->scrOld.push_back(m->scr);
+    m->scr = nb; m->scrCap = bytes;
     return m->scr;
 }
 
@@ -88,7 +91,9 @@ int orbm_create(orbm_t** out, int device_id) {
     orbm* m = new orbm;
     m->device = device_id;
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->e0) != hipSuccess ||
-        hipEventCreate(&m->e1) != hipSuccess || hipEventCreate(&m->e2) != hipSuccess) { set_merr("stream/event creation failed"); orbm_destroy(m); return ORBM_E_HIP; }
+        hipEventCreate(&m->e1) != hipSuccess || hipEventCreate(&m->e2) != hipSuccess ||
+        hipHostMalloc((void**)&m->hStatus, 64, hipHostMallocDefault) != hipSuccess) { set_merr("stream/event creation failed"); orbm_destroy(m); return ORBM_E_HIP; }
+    *m->hStatus = 0;
     m->ownStream = m->stream;
     *out = m;
     return ORBM_OK;
@@ -101,6 +106,8 @@ void orbm_destroy(orbm_t* m) {
     if (m->ownStream) { (void)hipStreamSynchronize(m->ownStream); (void)hipStreamDestroy(m->ownStream); }
     if (m->arDev) (void)hipFree(m->arDev);
     if (m->scr) (void)hipFree(m->scr);
+    for (uint8_t* p : m->scrOld) (void)hipFree(p);
+    if (m->hStatus) (void)hipHostFree(m->hStatus);
     if (m->arPin) (void)hipHostFree(m->arPin);
     if (m->e0) (void)hipEventDestroy(m->e0);
     if (m->e1) (void)hipEventDestroy(m->e1);
@@ -112,6 +119,12 @@ int orbm_sync(orbm_t* m) {
     if (!m) return ORBM_E_INVALID;
     MHIPCHK(hipSetDevice(m->device));
     MHIPCHK(hipStreamSynchronize(m->stream));
+    if (m->hStatus && *(volatile int*)m->hStatus) {             // set by a kernel of an enqueue-only call since the last sync
+        const int st = *(volatile int*)m->hStatus;
+        *(volatile int*)m->hStatus = 0;
+        set_merr("a batched call overflowed a device-side list (status 0x%x: 1 = stereo row lists): results of that call are incomplete", st);
+        return ORBM_E_CAPACITY;
+    }
     return ORBM_OK;
 }
 
@@ -343,6 +356,14 @@ int window_pass(orbm* m, const orbm_frame_t* f, int nq, const float* qx, const f
         set_merr("a search window returned more than %d candidates", devCap);
         return ORBM_E_CAPACITY;
     }
+    // Everything below indexes host arrays with what the device reported: counts beyond the row stride or keypoint indices
+    // beyond the frame must stop here, not in a caller's replay loop (round 2's ORBM_WINDOW_CAP=4 run died in such a loop,
+    // profiles/NOTES.md "18:59 segfault").
+    for (int i = 0; i < nq; ++i)
+        if (cnt[i] < 0 || cnt[i] > devCap) { set_merr("window %d reports %d candidates for a capacity of %d without the overflow flag", i, cnt[i], devCap); return ORBM_E_HIP; }
+    for (int i = 0; i < nq; ++i)
+        for (int c = 0; c < cnt[i]; ++c)
+            if ((unsigned)idx[(size_t)i * maxc + c] >= (unsigned)f->n) { set_merr("window %d candidate %d: keypoint index %d outside the frame (%d keypoints)", i, c, idx[(size_t)i * maxc + c], f->n); return ORBM_E_HIP; }
     cap = std::max(maxc, 1);
     return ORBM_OK;
 }
@@ -386,6 +407,16 @@ int window_topk_pass(orbm* m, const orbm_dframe* df, bool stereo_gate, int nq, c
     MHIPCHK(hipStreamSynchronize(m->stream));
     if (prof) fprintf(stderr, "orbm profile:   enqueue %.1f us, wait %.1f us (%s)\n", t1 - t0, T() - t1, copies ? "staged copies" : "zero-copy");
     *cnt = (const int*)dcnt.host(); *keys = (const unsigned int*)dkeys.host();
+    {   // the replays index the frame's arrays with the low 20 bits of every returned key: check them once, branch-free
+        const int* c_ = *cnt; const unsigned int* k_ = *keys;
+        unsigned bad = 0;
+        for (int i = 0; i < nq; ++i) {
+            const int nc = std::min(std::max(c_[i], 0), (int)WT_K);
+            bad |= (unsigned)(c_[i] < 0);
+            for (int c = 0; c < nc; ++c) bad |= (unsigned)((k_[(size_t)i * WT_K + c] & 0xFFFFFu) >= (unsigned)df->n);
+        }
+        if (bad) { set_merr("top-K window pass returned a keypoint index outside the resident frame (%d keypoints)", df->n); *cnt = nullptr; *keys = nullptr; return ORBM_E_HIP; }
+    }
     return ORBM_OK;
 }
 
@@ -475,7 +506,7 @@ int orbm_window_candidates(orbm_t* m, const orbm_frame_t* f, int nq, const float
 struct CandLists {
     const int* cnt = nullptr; const int* idx = nullptr; const int* dist = nullptr; int stride = 0;
     const unsigned int* keys = nullptr;                                 // dist << 20 | keypoint index, in (distance, visiting order) rank
-    int count(int i) const { return keys ? std::min(cnt[i], (int)WT_K) : cnt[i]; }
+    int count(int i) const { return keys ? std::min(cnt[i], (int)WT_K) : std::min(cnt[i], stride); }   // (never beyond a row: window_pass has checked)
     bool trunc(int i) const { return keys && cnt[i] > WT_K; }
     int index(int i, int c) const { return keys ? (int)(keys[(size_t)i * WT_K + c] & 0xFFFFFu) : idx[(size_t)i * stride + c]; }
     int distance(int i, int c) const { return keys ? (int)(keys[(size_t)i * WT_K + c] >> 20) : dist[(size_t)i * stride + c]; }
@@ -1575,11 +1606,19 @@ int orbm_stereo_batch_async(orbm_t* m, void* extractor, int first_l, int first_r
     int n2 = 64; while (n2 < cap) n2 <<= 1;
     if (n2 * 4 > 48 * 1024) MHIPCHK(hipFuncSetAttribute((const void*)k_stereo_cut, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 4));
     // vRowIndices (Frame.cc:1064-1083) of every right image as CSR in the handle's scratch: [npairs][nrows + 1] starts + [npairs][rowCap] indices
-    const int nrows = hl[0], rowCap = 16 * cap;                  // a band spans <= 2 * ceil(2 * 1.2^11) + 1 rows at 12 levels; 16 per keypoint is never reached at 8
+    // A keypoint enters rows floor(y - r) .. ceil(y + r), r = 2 * sf[octave] (Frame.cc:1071-1077): at most floor(2 r) + 3 rows (and never
+    // more than the image has), so [cap] keypoints of the coarsest level bound every right image's list.
+    float sfMax = 1.f;
+    for (int l = 0; l < nlev; ++l) sfMax = std::max(sfMax, B.sf[l]);
+    const int nrows = hl[0];
+    const long long perKp = std::min<long long>((long long)floorf(4.f * sfMax) + 3, nrows);
+    if (perKp * cap > 0x7fffffffLL) { set_merr("stereo row lists too large"); return ORBM_E_INVALID; }
+    const int rowCap = (int)(perKp * cap);
     const size_t bStart = ((size_t)npairs * (nrows + 1) * sizeof(int) + 255) & ~(size_t)255, bIdx = ((size_t)npairs * rowCap * sizeof(unsigned short) + 255) & ~(size_t)255;
     uint8_t* scr = batch_scratch(m, bStart + bIdx + 256);
     if (!scr) { set_merr("stereo scratch of %zu B unavailable (inside a capture, run the call once eagerly first)", bStart + bIdx + 256); return ORBM_E_HIP; }
-    int* rowStart = (int*)scr; unsigned short* rowIdx = (unsigned short*)(scr + bStart); int* rowErr = (int*)(scr + bStart + bIdx);
+    int* rowStart = (int*)scr; unsigned short* rowIdx = (unsigned short*)(scr + bStart);
+    int* rowErr = m->hStatus;                                    // cannot happen with the bound above; if it ever does, orbm_sync reports ORBM_E_CAPACITY
     const size_t ldsRows = (size_t)(2 * nrows + 2) * sizeof(int);
     if (ldsRows > 48 * 1024) MHIPCHK(hipFuncSetAttribute((const void*)k_stereo_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsRows));
     m->gridFirst = false;

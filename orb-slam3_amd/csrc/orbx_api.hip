@@ -14,8 +14,7 @@
 #include <condition_variable>
 #include <deque>
 #include <dlfcn.h>
-#include <hsa/hsa.h>
-#include <hsa/hsa_ext_amd.h>
+#include "hsa_copy.h"
 #include <chrono>
 #include <mutex>
 #include <thread>
@@ -154,6 +153,7 @@ struct orbx {
     int lastBatch = 0;
     int l0pitch = 0, lastL0Pitch = 0;
     std::vector<const u8*> hL0Ptr;
+    bool l0Staged = false;                                     // the last batch's level 0 was uploaded FROM hPinned (host images): its host copy is still there
     std::vector<int> hLap;
     bool timed = false;
 };
@@ -545,55 +545,13 @@ static inline hipEvent_t dep_ev(orbx* o, int i) { return o->capSlot < 0 ? o->ev[
 #define STAGE_EV(i, stream) do { if (o->stageTiming && o->capSlot < 0) HIPCHK(hipEventRecord(o->ev[i], stream)); } while (0)
 
 // ---- helper thread of the results-to-host copies (see struct orbx)
-// ---- The results-to-host copy goes through hsa_amd_memory_async_copy (a DMA engine).  hipMemcpyAsync is executed by this runtime as a
-// copy KERNEL, which beside the saturated extraction moves ~19 GB/s -- less than the stereo step produces (21 GB/s): C3 213 k -> 231 k
-// frames/s with the DMA engine, results identical.  The HSA runtime is the one HIP already loaded (dlopen by soname, no link
-// dependency); if it cannot be had, or a destination is not pinned memory it knows, the copy falls back to hipMemcpyAsync.
-// ORBX_DL_HSA=0: A/B switch.
-struct HsaCopy {
-    bool ok = false;
-    hsa_status_t (*init)() = nullptr;
-    hsa_status_t (*ptrinfo)(const void*, hsa_amd_pointer_info_t*, void* (*)(size_t), uint32_t*, hsa_agent_t**) = nullptr;
-    hsa_status_t (*sigcreate)(hsa_signal_value_t, uint32_t, const hsa_agent_t*, hsa_signal_t*) = nullptr;
-    void (*sigstore)(hsa_signal_t, hsa_signal_value_t) = nullptr;
-    hsa_signal_value_t (*sigwait)(hsa_signal_t, hsa_signal_condition_t, hsa_signal_value_t, uint64_t, hsa_wait_state_t) = nullptr;
-    hsa_status_t (*copy)(void*, hsa_agent_t, const void*, hsa_agent_t, size_t, uint32_t, const hsa_signal_t*, hsa_signal_t) = nullptr;
-    hsa_signal_t sig{};
-    hsa_status_t (*sigdestroy)(hsa_signal_t) = nullptr;
-    ~HsaCopy() { if (ok && sigdestroy) (void)sigdestroy(sig); }
-    bool load() {
-        void* h = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) return false;
-        init = (decltype(init))dlsym(h, "hsa_init"); ptrinfo = (decltype(ptrinfo))dlsym(h, "hsa_amd_pointer_info");
-        sigcreate = (decltype(sigcreate))dlsym(h, "hsa_signal_create"); sigstore = (decltype(sigstore))dlsym(h, "hsa_signal_store_relaxed");
-        sigwait = (decltype(sigwait))dlsym(h, "hsa_signal_wait_scacquire"); copy = (decltype(copy))dlsym(h, "hsa_amd_memory_async_copy");
-        sigdestroy = (decltype(sigdestroy))dlsym(h, "hsa_signal_destroy");
-        if (!init || !ptrinfo || !sigcreate || !sigstore || !sigwait || !copy) return false;
-        if (init() != HSA_STATUS_SUCCESS || sigcreate(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return false;
-        return ok = true;
-    }
-    // n pieces, all device -> pinned host; returns false if any piece cannot go this way (nothing copied then is waited for anyway)
-    bool run(void* const* dst, const void* const* src, const size_t* bytes, int n) {
-        sigstore(sig, n);
-        int issued = 0;
-        bool good = true;
-        for (int i = 0; i < n && good; ++i) {
-            hsa_amd_pointer_info_t ps{}, pd{}; ps.size = sizeof ps; pd.size = sizeof pd;
-            good = ptrinfo(src[i], &ps, nullptr, nullptr, nullptr) == HSA_STATUS_SUCCESS && ptrinfo(dst[i], &pd, nullptr, nullptr, nullptr) == HSA_STATUS_SUCCESS &&
-                   ps.type != HSA_EXT_POINTER_TYPE_UNKNOWN && pd.type != HSA_EXT_POINTER_TYPE_UNKNOWN &&
-                   copy(dst[i], pd.agentOwner, src[i], ps.agentOwner, bytes[i], 0, nullptr, sig) == HSA_STATUS_SUCCESS;
-            if (good) ++issued;
-        }
-        if (issued < n) sigstore(sig, issued);   // (pieces not issued never signal)
-        if (issued) while (sigwait(sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) != 0) {}
-        return good;
-    }
-};
-
+// ---- The results-to-host copy goes through hsa_amd_memory_async_copy (a DMA engine): hsa_copy.h.  If the HSA runtime cannot be had, or a
+// destination is not pinned memory it knows, the copy falls back to hipMemcpyAsync.
 static void dl_worker(orbx* o) {
     (void)hipSetDevice(o->device);
     HsaCopy hsa;
     bool useHsa = !(getenv("ORBX_DL_HSA") && atoi(getenv("ORBX_DL_HSA")) == 0) && !o->dlKernel && hsa.load();
+    if (getenv("ORBX_DL_TIMEOUT_MS")) hsa.timeoutMs = atof(getenv("ORBX_DL_TIMEOUT_MS"));
     for (;;) {
         orbx::DlReq r;
         {
@@ -609,7 +567,9 @@ static void dl_worker(orbx* o) {
             int n = 0;
             dst[n] = r.host; src[n] = o->rb[r.block].base; nb[n] = o->blockBytes; ++n;
             for (const orbx::Attach& a : o->attach[r.block]) { dst[n] = (u8*)r.host + a.hostOff; src[n] = a.dev; nb[n] = a.bytes; ++n; }
-            done = hsa.run(dst, src, nb, n);
+            const HsaCopy::Result r_ = hsa.run(dst, src, nb, n);
+            done = r_ == HsaCopy::DONE;
+            if (r_ == HsaCopy::TIMEOUT) e = hipErrorLaunchTimeOut;   // issued DMA never completed: ORBX_E_HIP at the next orbx_sync / block wait, no silent fallback
             if (!done) useHsa = false;                           // e.g. a pageable destination: the runtime's own copy handles it (all pieces again)
         }
         if (e == hipSuccess && !done) {
@@ -817,7 +777,9 @@ static int extract_batch_async_impl(orbx_t* o, const uint8_t* const* imgs, int i
     if (img_space == ORBX_DEVICE && aligned) {
         for (int i = 0; i < nimg; ++i) o->hL0Ptr[i] = imgs[i];
         l0pitch = stride;
+        o->l0Staged = false;
     } else if (img_space == ORBX_DEVICE) {                    // kernels use 16-byte row loads: stage misaligned inputs
+        o->l0Staged = false;                                  // dL0 is filled device-to-device: hPinned (if any) holds an OLDER host batch
         for (int i = 0; i < nimg; ++i) {
             u8* d = o->dL0 + (size_t)i * o->l0pitch * h;
             HIPCHK(hipMemcpy2DAsync(d, o->l0pitch, imgs[i], stride, w, h, hipMemcpyDeviceToDevice, st));
@@ -846,6 +808,7 @@ static int extract_batch_async_impl(orbx_t* o, const uint8_t* const* imgs, int i
         HIPCHK(hipMemcpyAsync(o->dL0, o->hPinned, need, hipMemcpyHostToDevice, st));
         HIPCHK(hipEventRecord(o->evH2D, st));
         l0pitch = o->l0pitch;
+        o->l0Staged = true;
     }
     for (int i = 0; i < nimg; ++i) { o->hLap[2 * i] = lap01 ? lap01[2 * i] : 0; o->hLap[2 * i + 1] = lap01 ? lap01[2 * i + 1] : 0; }
     // the per-frame pointer and lapping tables are re-uploaded only when they change (a streaming caller cycling through
@@ -1249,6 +1212,9 @@ static void one_launch_fetch(orbx* o) {
 // them hipGraph places the nodes so that the replay is no faster than the eager path -- 0.193 instead of 0.170 ms, measured.)
 // capture the sequence for the current geometry into the private slot; on any failure the handle stays on the eager path for good
 static void one_capture(orbx* o, int w, int h) {
+    // the captured call below takes level 0 as a device image (dL0); the frame in it was uploaded from hPinned by the eager call
+    // that led here and the capture does not change that, so the "host copy still staged" state survives this function
+    struct KeepStaged { orbx* o; bool v; ~KeepStaged() { o->l0Staged = v; } } keepStaged{o, o->l0Staged};
     const int slot = orbx::kSlots;
     orbx::GraphSlot& G = o->gs[slot];
     if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
@@ -1323,7 +1289,7 @@ int orbx_extract(orbx_t* o, const uint8_t* img, int w, int h, int stride, int la
         HIPCHK(hipGraphLaunch(G.exec, o->stream));
         ++G.launches;
         { const int rc = orbx_set_result_block(o, G.block); if (rc) return rc; }
-        o->hL0Ptr[0] = o->dL0; o->lastL0Pitch = o->l0pitch;
+        o->hL0Ptr[0] = o->dL0; o->lastL0Pitch = o->l0pitch; o->l0Staged = true;
         o->hLap[0] = lap0; o->hLap[1] = lap1; o->upLap.assign(lap, lap + 2);
         o->lastBatch = 1; o->countsValid = false; o->timed = true; o->graphMode = true;
         HIPCHK(hipStreamSynchronize(o->stream));
@@ -1417,7 +1383,7 @@ int orbx_pyramid_fetch(orbx_t* o, int frame, uint8_t* const* dst, const int* dst
         if (!dst[l]) continue;
         if (l == 0) {
             const u8* src = o->hL0Ptr[frame];
-            const bool staged = o->hPinned && src >= o->dL0 && src < o->dL0 + o->capL0 && (size_t)(src - o->dL0) + (size_t)o->l0pitch * D.h <= o->capPinned;
+            const bool staged = o->l0Staged && o->hPinned && src >= o->dL0 && src < o->dL0 + o->capL0 && (size_t)(src - o->dL0) + (size_t)o->l0pitch * D.h <= o->capPinned;
             if (staged) {                                        // the host copy of what was uploaded is still in the staging buffer
                 const u8* hp = o->hPinned + (src - o->dL0);
                 for (int y = 0; y < D.h; ++y) memcpy(dst[0] + (size_t)y * dst_stride[0], hp + (size_t)y * o->l0pitch, (size_t)D.w);
@@ -1450,7 +1416,7 @@ int orbx_pyramid_map(orbx_t* o, int frame, const uint8_t** ptr, int* pitch) {
     if (g.nlevels > 1) HIPCHK(hipMemcpyAsync(o->hPyr, o->dPyr + (size_t)frame * g.pyrFrameBytes, g.pyrFrameBytes, hipMemcpyDeviceToHost, o->stream));
     HIPCHK(hipStreamSynchronize(o->stream));
     const u8* src = o->hL0Ptr[frame];
-    const bool staged = o->hPinned && src >= o->dL0 && src < o->dL0 + o->capL0 && (size_t)(src - o->dL0) + (size_t)o->l0pitch * g.lv[0].h <= o->capPinned;
+    const bool staged = o->l0Staged && o->hPinned && src >= o->dL0 && src < o->dL0 + o->capL0 && (size_t)(src - o->dL0) + (size_t)o->l0pitch * g.lv[0].h <= o->capPinned;
     ptr[0] = staged ? o->hPinned + (src - o->dL0) : nullptr; pitch[0] = staged ? o->l0pitch : 0;
     for (int l = 1; l < g.nlevels; ++l) { ptr[l] = o->hPyr + g.lv[l].off; pitch[l] = g.lv[l].pitch; }
     return ORBX_OK;

@@ -440,7 +440,14 @@ public:
 
     // ------------------------------------------------------------------------------------------------------------------
     // M10 SearchForTriangulation_(pKF1, pKF2, cv::Matx33f F12, vMatchedPairs, bOnlyStereo, bCoarse)   (ORBmatcher.cc:1388-1629)
-    //     pinhole cameras; with a second camera (pKF1->mpCamera2) the four-pose gate of :1413-1426, 1526-1557
+    //     The reference never reads F12: its geometric gate is the VIRTUAL pCamera1->epipolarConstrain_(pCamera2, kp1, kp2,
+    //     R12, t12, ...) (:1555).  Dispatch on the camera model as that call does:
+    //       * both KeyFrames single-camera Pinhole: Pinhole::epipolarConstrain_ (Pinhole.cpp:273-299) rebuilds
+    //         K1^-T [t12]x R12 K2^-1 from the same R12 / t12 -- the very expression LocalMapping::ComputeF12_
+    //         (LocalMapping.cc:1102-1119) hands in as F12 -- and tests the epipolar-line distance: device fast path;
+    //       * a single camera of any other model (monocular KannalaBrandt8: TriangulateMatches_ > 0.0001f,
+    //         KannalaBrandt8.cpp:356-360): the bucket search with the camera object's own gate, R12 / t12 as :1413-1416;
+    //       * a second camera (mpCamera2): the four-pose gate of :1417-1426, 1526-1557.
     // ------------------------------------------------------------------------------------------------------------------
     template <class KeyFrameT>
     int SearchForTriangulation_(KeyFrameT* pKF1, KeyFrameT* pKF2, cv::Matx33f F12, std::vector<std::pair<size_t, size_t>>& vMatchedPairs,
@@ -452,9 +459,40 @@ public:
         auto t2w = pKF2->GetTranslation_();
         auto C2 = R2w * Cw + t2w;
         cv::Point2f ep = pKF2->mpCamera->project(C2);
+        const bool pinhole = pKF1->mpCamera->GetType() == pKF1->mpCamera->CAM_PINHOLE && pKF2->mpCamera->GetType() == pKF2->mpCamera->CAM_PINHOLE;
+        if (!pinhole) return SearchForTriangulationOneCamera_(pKF1, pKF2, ep, vMatchedPairs, bOnlyStereo, bCoarse);
         float F[9];
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) F[3 * i + j] = F12(i, j);
         return triangulation(pKF1, pKF2, F, ep, vMatchedPairs, bOnlyStereo, bCoarse, false);
+    }
+
+    // SearchForTriangulation_ for single-camera KeyFrames whose camera model is not Pinhole.  Loop conditions in the
+    // reference's order: MapPoint / bOnlyStereo skips (:1458-1466, 1488-1497, folded into the skip flags of the bucket
+    // search: both are plain `continue`s on the feature), TH_LOW / bestDist (:1503-1504, on the device), the epipole gate
+    // (:1512-1520, !bStereo1 && !bStereo2 && !mpCamera2), then pCamera1->epipolarConstrain_(pCamera2, ...) || bCoarse (:1555).
+    template <class KeyFrameT>
+    int SearchForTriangulationOneCamera_(KeyFrameT* pKF1, KeyFrameT* pKF2, const cv::Point2f& ep, std::vector<std::pair<size_t, size_t>>& vMatchedPairs,
+                                         const bool bOnlyStereo, const bool bCoarse) {
+        const cv::Matx33f R1w = pKF1->GetRotation_(), R2w = pKF2->GetRotation_();
+        const cv::Matx31f t1w = pKF1->GetTranslation_(), t2w = pKF2->GetTranslation_();
+        const cv::Matx33f R12 = R1w * R2w.t();                                              // :1414
+        const cv::Matx31f t12 = -R1w * R2w.t() * t2w + t1w;                                 // :1415
+        auto* pCamera1 = pKF1->mpCamera; auto* pCamera2 = pKF2->mpCamera;
+        auto key = [](KeyFrameT* kf, int i) -> const cv::KeyPoint& {
+            return kf->NLeft == -1 ? kf->mvKeysUn[i] : i < kf->NLeft ? kf->mvKeys[i] : kf->mvKeysRight[i - kf->NLeft];
+        };
+        auto gate = [&](int idx1, int idx2) -> bool {
+            const cv::KeyPoint& kp1 = key(pKF1, idx1); const cv::KeyPoint& kp2 = key(pKF2, idx2);
+            const bool bStereo1 = pKF1->mvuRight[idx1] >= 0, bStereo2 = pKF2->mvuRight[idx2] >= 0;
+            if (!bStereo1 && !bStereo2) {
+                const float distex = ep.x - kp2.pt.x;
+                const float distey = ep.y - kp2.pt.y;
+                if (distex * distex + distey * distey < 100 * pKF2->mvScaleFactors[kp2.octave]) return false;
+            }
+            return pCamera1->epipolarConstrain_(pCamera2, kp1, kp2, R12, t12, pKF1->mvLevelSigma2[kp1.octave], pKF2->mvLevelSigma2[kp2.octave]) || bCoarse;
+        };
+        auto skip = [bOnlyStereo](KeyFrameT* kf, int i) -> bool { return bOnlyStereo && !(kf->mvuRight[i] >= 0); };
+        return SearchForTriangulationGated(pKF1, pKF2, gate, vMatchedPairs, skip);
     }
 
     // M11 SearchForTriangulation(pKF1, pKF2, cv::Mat F12, vMatchedPairs, bOnlyStereo, bCoarse)   (ORBmatcher.cc:1107-1386)
@@ -478,6 +516,11 @@ public:
     // as the reference does (:1467-1469): mvKeysUn when NLeft == -1, else mvKeys followed by mvKeysRight.
     template <class KeyFrameT, class Gate>
     int SearchForTriangulationGated(KeyFrameT* pKF1, KeyFrameT* pKF2, Gate&& gate, std::vector<std::pair<size_t, size_t>>& vMatchedPairs) {
+        return SearchForTriangulationGated(pKF1, pKF2, gate, vMatchedPairs, [](KeyFrameT*, int) { return false; });
+    }
+    // `skip(kf, idx)`: features the reference passes over with a `continue` next to the MapPoint test (bOnlyStereo, :1464-1466, 1494-1497)
+    template <class KeyFrameT, class Gate, class Skip>
+    int SearchForTriangulationGated(KeyFrameT* pKF1, KeyFrameT* pKF2, Gate&& gate, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, Skip&& skip) {
         auto keys = [](KeyFrameT* kf, std::vector<cv::KeyPoint>& tmp) -> const cv::KeyPoint* {
             if (kf->NLeft == -1) return kf->mvKeysUn.data();
             tmp.assign(kf->mvKeys.begin(), kf->mvKeys.begin() + kf->NLeft);
@@ -486,8 +529,8 @@ public:
         };
         facade_detail::FlatFeatVec<decltype(pKF1->mFeatVec)> f1(pKF1->mFeatVec), f2(pKF2->mFeatVec);
         std::vector<uint8_t> mp1(pKF1->N > 0 ? pKF1->N : 1), mp2(pKF2->N > 0 ? pKF2->N : 1);
-        for (int i = 0; i < pKF1->N; ++i) mp1[i] = pKF1->GetMapPoint(i) != nullptr;
-        for (int i = 0; i < pKF2->N; ++i) mp2[i] = pKF2->GetMapPoint(i) != nullptr;
+        for (int i = 0; i < pKF1->N; ++i) mp1[i] = pKF1->GetMapPoint(i) != nullptr || skip(pKF1, i);
+        for (int i = 0; i < pKF2->N; ++i) mp2[i] = pKF2->GetMapPoint(i) != nullptr || skip(pKF2, i);
         std::vector<cv::KeyPoint> t1, t2;
         const cv::KeyPoint* k1 = keys(pKF1, t1); const cv::KeyPoint* k2 = keys(pKF2, t2);
         std::vector<int32_t> m12(pKF1->N > 0 ? pKF1->N : 1, -1);

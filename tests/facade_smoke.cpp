@@ -22,7 +22,19 @@ struct MockCamera {                                             // Pinhole (Came
     cv::Point2f project(const cv::Point3f& p) const { return cv::Point2f(fx * p.x / p.z + cx, fy * p.y / p.z + cy); }
     cv::Point2f project(const cv::Mat& m) const { return project(cv::Point3f(m.at<float>(0), m.at<float>(1), m.at<float>(2))); }
     cv::Point2f project(const cv::Matx31f& m) const { return project(cv::Point3f(m(0), m(1), m(2))); }
-    bool epipolarConstrain_(MockCamera*, const cv::KeyPoint&, const cv::KeyPoint&, const cv::Matx33f&, const cv::Matx31f&, float, float) { return true; }
+    // GeometricCamera.h:82-85: GetType() and the two type constants are (non-static) members of the camera object
+    unsigned int mnType = 0;
+    unsigned int GetType() { return mnType; }
+    const unsigned int CAM_PINHOLE = 0;
+    const unsigned int CAM_FISHEYE = 1;
+    // a non-pinhole mock (mnType = CAM_FISHEYE) answers with a test that is NOT an epipolar-line distance, so that the
+    // outcome shows which gate the matcher consulted (KannalaBrandt8::epipolarConstrain_ triangulates, KannalaBrandt8.cpp:356-360)
+    int gateCalls = 0;
+    cv::Matx33f lastR12; cv::Matx31f lastT12;
+    bool epipolarConstrain_(MockCamera*, const cv::KeyPoint& kp1, const cv::KeyPoint&, const cv::Matx33f& R12, const cv::Matx31f& t12, float, float) {
+        ++gateCalls; lastR12 = R12; lastT12 = t12;
+        return mnType == 0 ? true : kp1.pt.y < 240.f;
+    }
     bool matchAndtriangulate(const cv::KeyPoint&, const cv::KeyPoint&, MockCamera*, cv::Mat&, cv::Mat&, float, float, cv::Mat& x3D) { x3D = cv::Mat(3, 1, CV_32F); return true; }
 };
 
@@ -313,6 +325,37 @@ int main(int argc, char** argv) {
         std::printf("facade: M10 SearchForTriangulation_ %d (flattened %d), M11 legacy overload %d\n", a, c, b);
         CHECK(a == c && a > n / 2 && (int)pairs.size() == a && b > n / 2 && (int)pairsL.size() == b, 47);
         for (auto& pr : pairs) CHECK(want[pr.first] == (int)pr.second, 48);
+    }
+    {   // ---- M10 on single-camera KeyFrames whose camera is NOT a pinhole (monocular fisheye, Examples/Monocular/TUM_512.yaml):
+        //      the reference's gate is the virtual pCamera1->epipolarConstrain_ (ORBmatcher.cc:1555), not the F12 line test
+        resetPoints();
+        MockCamera fish; fish.mnType = fish.CAM_FISHEYE;
+        MockKeyFrame K1, K2; makeKF(K1, false); makeKF(K2, false);
+        K1.mpCamera = &fish; K2.mpCamera = &fish;
+        K2.Tcw.at<float>(0, 3) = -0.2f;
+        cv::Matx33f F12; F12(1, 2) = 0.2f; F12(2, 1) = -0.2f;    // what the line test would use: it accepts every pair of this scene (previous block)
+        std::vector<std::pair<size_t, size_t>> pairs, pairsC, pairsS;
+        Matcher mm(0.6f, false);
+        const int got = mm.SearchForTriangulation_(&K1, &K2, F12, pairs, false, false);
+        CHECK(fish.gateCalls > 0, 60);                           // the camera object was consulted ...
+        CHECK(got > 0 && (int)pairs.size() == got, 61);
+        int upper = 0; for (int i = 0; i < n; ++i) upper += kps[i].pt.y < 240.f;
+        for (auto& pr : pairs) CHECK(K1.mvKeysUn[pr.first].pt.y < 240.f, 62);   // ... and its answer decided (the line test passes the lower half too)
+        CHECK(got <= upper && got < n, 63);
+        CHECK(fish.lastR12(0, 0) == 1.f && fish.lastR12(1, 1) == 1.f && fish.lastT12(0) == 0.2f && fish.lastT12(1) == 0.f, 64);   // R12 = R1w R2w^T, t12 = -R1w R2w^T t2w + t1w (:1414-1415)
+        // the same search through the flattened gated entry point with the epipole + camera gate written out
+        const cv::Point2f ep = fish.project(cv::Point3f(-0.2f, 0.f, 0.f));
+        const int want = mm.SearchForTriangulationGated(&K1, &K2, [&](int i1, int i2) {
+            const float dx = ep.x - kps[i2].pt.x, dy = ep.y - kps[i2].pt.y;
+            if (dx * dx + dy * dy < 100 * sf[kps[i2].octave]) return false;
+            return kps[i1].pt.y < 240.f; }, pairsS);
+        CHECK(want == got && pairsS == pairs, 65);
+        const int calls0 = fish.gateCalls;
+        const int coarse = mm.SearchForTriangulation_(&K1, &K2, F12, pairsC, false, true);   // || bCoarse (:1555): the camera is still asked first
+        CHECK(fish.gateCalls > calls0 && coarse >= got && coarse > n / 2, 66);
+        const int only = mm.SearchForTriangulation_(&K1, &K2, F12, pairsC, true, true);      // bOnlyStereo on monocular KeyFrames: every feature skipped (:1464-1466)
+        CHECK(only == 0 && pairsC.empty(), 67);
+        std::printf("facade: M10 non-pinhole single camera: %d matches through the camera's own gate (%d gate calls), %d coarse\n", got, fish.gateCalls, coarse);
     }
     {   // ---- M10 with two cameras / M12: the gated bucket search
         MockKeyFrame a, b;
