@@ -12,7 +12,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <array>
 #include <deque>
+#include <map>
 #include <dlfcn.h>
 #include "hsa_copy.h"
 #include <chrono>
@@ -55,10 +57,14 @@ struct orbx {
     BlurSel blurSel;
     std::vector<StripInfo> strips;
     StripInfo* dStrips = nullptr; size_t capStrips = 0;
+    std::vector<CellAux> aux; std::vector<F4Item> f4items;    // k_fast4: per-cell scalars and per-shape item tables
+    CellAux* dAux = nullptr; size_t capAux = 0;
+    F4Item* dF4Items = nullptr; size_t capF4Items = 0;
+    bool fastV3 = false;                                      // ORBX_FAST_V3: A/B, k_fast3 instead of k_fast4
     bool fastV1 = false;
     // k_fast3 launch groups: level 0 (needs no resize), the fine levels, the coarse levels.  Each group sizes its own LDS
     // (tile of its tallest cell row + survivor queues), because occupancy -- 20 vs 28 waves per CU -- is worth ~15 %.
-    struct F3Group { int strip0 = 0, nstrips = 0, tile = 0, qcap = 0, lastLevel = 0, pitch = 0; size_t lds = 0; };   // pitch: 176 / 208 = compile-time tile pitch of the group, 0 = per strip
+    struct F3Group { int strip0 = 0, nstrips = 0, tile = 0, qcap = 0, lastLevel = 0, pitch = 0; size_t lds = 0; bool v4 = false; };   // pitch: 176 / 208 = compile-time tile pitch of the group, 0 = per strip
     hipEvent_t evLvl[12] = {};                                // "pyramid level l is resized" for the levels that end a FAST group
     std::vector<F3Group> f3g;
     std::vector<int> stripTile, stripQ;                       // per strip: tile bytes, worst-case queue entries
@@ -513,10 +519,60 @@ static int build_geometry(orbx* o, int w, int h) {
             }
             if (o->f3QcapForce > 0) G.qcap = std::min(G.qcap, align_up(o->f3QcapForce, 64));
             G.lds = (size_t)2 * G.tile + (size_t)(F3_NT / 64) * G.qcap * 2;
+            if (const char* e = getenv("ORBX_FAST_LDSPAD")) G.lds += (size_t)atoi(e);   // experiment: occupancy sensitivity
             if (G.lds > 160 * 1024 - 256) { set_err("FAST strip needs %zu B of LDS", G.lds); return ORBX_E_UNSUPPORTED; }
             maxLds = std::max(maxLds, G.lds);
             o->f3g.push_back(G);
         }
+        // k_fast4 tables: per cell the scalars a wave needs, per distinct cell shape (pitch, window width, window height, column
+        // phase) the lane -> (tile bytes, valid pixels, queue-entry base) list of every quick-pass iteration
+        o->aux.assign(o->cells.size(), CellAux{});
+        o->f4items.clear();
+        std::map<std::array<int, 4>, u32> shapes;
+        for (orbx::F3Group& G : o->f3g) {
+            G.v4 = !o->fastV3;
+            for (int si = G.strip0; si < G.strip0 + G.nstrips && G.v4; ++si) {
+                const StripInfo& stp = o->strips[si];
+                const int Pb = G.pitch ? G.pitch : (int)stp.lp;
+                for (int k = 0; k < stp.ncell && G.v4; ++k) {
+                    const CellInfo& c = o->cells[stp.cell0 + k];
+                    CellAux& A = o->aux[stp.cell0 + k];
+                    A.slot = c.slot; A.cnt = c.cnt;
+                    const int cx0 = c.x0 + 3 - stp.xal, vw = c.cw - 6, vh = stp.h - 6;
+                    if (vw <= 0 || vh <= 0) { A.nit = 0; continue; }
+                    const int a = cx0 & 3, s4 = cx0 - a, ncol = (a + vw + 7) / 8, nitems = vh * ncol, nit = (nitems + 63) / 64;
+                    // limits of the 16-bit fields (entry: 7-bit row, 7-bit xs; item: 16-bit tile offset); beyond them the group stays on k_fast3
+                    if (ncol > 16 || vh > 127 || (vh - 1) * Pb + 8 * (ncol - 1) > 65535 || 3 * Pb + s4 > 65535 || s4 < 4) { G.v4 = false; break; }
+                    const std::array<int, 4> key = {Pb, vw, vh, a};
+                    auto itS = shapes.find(key);
+                    if (itS == shapes.end()) {
+                        const u32 t0 = (u32)o->f4items.size();
+                        o->f4items.resize(t0 + (size_t)nit * 64);
+                        for (int i = 0; i < nit * 64; ++i) {
+                            F4Item& I = o->f4items[t0 + i];
+                            I.mask = 0; I.offq = 0;
+                            if (i >= nitems) continue;                  // idle lane of the last iteration: reads (row 0, column 0), keeps nothing
+                            const int row = i / ncol, col = i % ncol;
+                            for (int px = 0; px < 8; ++px) { const int xs = 8 * col + px; if (xs >= a && xs < a + vw) I.mask |= 1u << (4 * px + 3); }
+                            I.offq = (u32)(row * Pb + 8 * col) | ((u32)((row << 9) | (col << 5)) << 16);
+                        }
+                        itS = shapes.emplace(key, t0).first;
+                    }
+                    A.tab = itS->second;
+                    A.base = (u16)(3 * Pb + s4); A.nit = (u16)nit;
+                    A.outx = (short)(c.x0 + 3 - 16 - a); A.outy = (short)(stp.y0 + 3 - 16);
+                    A.xlo = (u16)a; A.xhi = (u16)(a + vw - 1);
+                }
+            }
+        }
+        if (o->f4items.empty()) o->f4items.push_back(F4Item{0, 0});
+        if (ensure(&o->dAux, &o->capAux, o->aux.size())) return ORBX_E_HIP;
+        if (ensure(&o->dF4Items, &o->capF4Items, o->f4items.size())) return ORBX_E_HIP;
+        HIPCHK(hipMemcpy(o->dAux, o->aux.data(), o->aux.size() * sizeof(CellAux), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(o->dF4Items, o->f4items.data(), o->f4items.size() * sizeof(F4Item), hipMemcpyHostToDevice));
+        HIPCHK(hipFuncSetAttribute((const void*)k_fast4<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_fast4<176>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_fast4<208>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
         HIPCHK(hipFuncSetAttribute((const void*)k_fast3<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
         HIPCHK(hipFuncSetAttribute((const void*)k_fast3<176>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
         HIPCHK(hipFuncSetAttribute((const void*)k_fast3<208>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
@@ -646,6 +702,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     o->odV1 = getenv("ORBX_OD_V1") != nullptr;
     if (const char* e = getenv("ORBX_FAST_QCAP")) o->f3QcapForce = atoi(e);
     o->f3NoFixedPitch = getenv("ORBX_FAST_PITCH0") != nullptr;
+    o->fastV3 = getenv("ORBX_FAST_V3") != nullptr;
     if (const char* e = getenv("ORBX_QT_WIDE")) o->qtWideForce = atoi(e) != 0 ? 1 : 0;
     o->blurEarly = !o->blurV2 && getenv("ORBX_BLUR_LATE") == nullptr;
     o->blurTiled = !o->blurV2 && !o->odV1 && getenv("ORBX_BLUR_ROWMAJOR") == nullptr;
@@ -726,7 +783,7 @@ void orbx_destroy(orbx_t* o) {
     for (auto& e : o->evMark) if (e) (void)hipEventDestroy(e);
     for (auto& e : o->evBatchDone) if (e) (void)hipEventDestroy(e);
     if (o->stream3) (void)hipStreamDestroy(o->stream3);
-    void* ptrs[] = {o->dPyr, o->dBlur, o->dL0, (void*)o->dL0Ptr, o->dCells, o->dTiles, o->dTiles3, o->dB3Th, o->dB3Tv, o->dStrips, o->dX4, o->dRzTasks, o->dXt, o->dYt, o->dCandCnt, o->dCandEnt,
+    void* ptrs[] = {o->dPyr, o->dBlur, o->dL0, (void*)o->dL0Ptr, o->dCells, o->dTiles, o->dTiles3, o->dB3Th, o->dB3Tv, o->dStrips, o->dAux, o->dF4Items, o->dX4, o->dRzTasks, o->dXt, o->dYt, o->dCandCnt, o->dCandEnt,
                     o->dSel, o->dSelCnt, o->dKpNode, o->dDense, o->rb[0].base, o->rb[1].base, o->rb[2].base, o->rb[3].base, o->rb[4].base, o->rb[5].base, o->rb[6].base, o->rb[7].base, o->dWork, o->dLap, o->dErr, o->dPattern, o->dOvf, o->dOvfList, o->dOdW, (void*)o->dStamps};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& set : o->evr) for (auto& e : set) if (e) (void)hipEventDestroy(e);
@@ -867,9 +924,15 @@ static int extract_batch_async_impl(orbx_t* o, const uint8_t* const* imgs, int i
                 if (first) STAGE_EV(1, st);
                 first = false;
             }
-            auto kern = G.pitch == 176 ? k_fast3<176> : G.pitch == 208 ? k_fast3<208> : k_fast3<0>;
-            hipLaunchKernelGGL(kern, dim3((unsigned)G.nstrips, nimg), dim3(F3_NT), G.lds, st, g, o->dL0Ptr, l0pitch, o->dPyr,
-                               o->dCells, o->dStrips + G.strip0, o->dCandCnt, o->dCandEnt, o->dErr, G.tile, G.qcap, o->dOvf, o->dOvfList);
+            if (G.v4) {
+                auto kern = G.pitch == 176 ? k_fast4<176> : G.pitch == 208 ? k_fast4<208> : k_fast4<0>;
+                hipLaunchKernelGGL(kern, dim3((unsigned)G.nstrips, nimg), dim3(F3_NT), G.lds, st, g, o->dL0Ptr, l0pitch, o->dPyr,
+                                   o->dAux, o->dF4Items, o->dStrips + G.strip0, o->dCandCnt, o->dCandEnt, o->dErr, G.tile, G.qcap, o->dOvf, o->dOvfList);
+            } else {
+                auto kern = G.pitch == 176 ? k_fast3<176> : G.pitch == 208 ? k_fast3<208> : k_fast3<0>;
+                hipLaunchKernelGGL(kern, dim3((unsigned)G.nstrips, nimg), dim3(F3_NT), G.lds, st, g, o->dL0Ptr, l0pitch, o->dPyr,
+                                   o->dCells, o->dStrips + G.strip0, o->dCandCnt, o->dCandEnt, o->dErr, G.tile, G.qcap, o->dOvf, o->dOvfList);
+            }
         }
         if (first) {                                             // single-level extractor
             STAGE_EV(10, st);

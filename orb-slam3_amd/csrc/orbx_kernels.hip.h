@@ -690,6 +690,294 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_fast4: k_fast3 on an instruction diet (round 3).  Same algorithm, same order, same outputs; what changed:
+//   * the quick reject walks a cell as ONE linear list of (row, 8-px column) items, 64 per wave-iteration, with the columns
+//     starting at a 4-px boundary: a 36 x 38-px window is 5 columns x 38 rows = 190 items = 3 iterations at 99 % lane use
+//     (k_fast3: lane -> fixed 8-aligned column, 6 columns x 10 rows per iteration: 4 iterations, 66 % of the lanes on valid
+//     pixels);
+//   * everything that depends only on the cell's SHAPE -- which tile bytes a lane reads in iteration i, which of its 8 pixels
+//     lie inside the window, the (row, column) part of its queue entries -- comes from a host-built table (F4Item, one 8-byte
+//     load per lane and iteration, shared by all cells of that shape and therefore L1-resident); what depends on the cell
+//     comes through the scalar cache (CellAux).  The per-cell set-up of k_fast3 (two IEEE divides, magic reciprocals,
+//     column masks: ~80 VALU) is gone;
+//   * LDS addresses are 32-bit offsets from window corners, so that every ring / neighbour read is base + immediate (k_fast3:
+//     18 address adds per scored pixel pair, a 64-bit multiply-add per quick iteration);
+//   * the tile load reads clamped addresses instead of predicating (columns right of the image only reach masked pixels).
+// Queue entry (u16): row << 9 | xs << 2 | 3, xs = column relative to the cell's first 4-aligned column (so xs = 8 * col + k and
+// the low five bits are the sparse mask's bit index 4k + 3: the append loop ORs the bit position in, no shift).
+// ------------------------------------------------------------------------------------------------
+struct CellAux {                                            // 32 bytes, read with one scalar load
+    u32 tab;                                                // first F4Item of the cell's shape table: [nit][64]
+    int slot, cnt;                                          // as CellInfo
+    u16 base;                                               // tile byte offset of (row 0, xs 0): 3 * pitch + s4
+    u16 nit;                                                // quick-pass iterations (0: empty window)
+    short outx, outy;                                       // packed output coordinates of (row 0, xs 0)
+    u16 xlo, xhi;                                           // xs of the window's first / last column
+    u32 pad[2];
+};
+struct F4Item { u32 mask; u32 offq; };                      // mask: pixel k of the lane's 8 inside the window -> bit 4k+3; offq: lo16 = row * pitch + 8 * col, hi16 = row << 9 | col << 5
+
+// LDS accesses of k_fast4 by ABSOLUTE 32-bit LDS address (base of the dynamic allocation folded into wave-uniform offsets once):
+// `shared_array + offset` makes the compiler add the array's (zero) address per access and widen pointer arithmetic to 64 bits.
+typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
+typedef __attribute__((address_space(3))) unsigned short lds_u16_t;
+typedef __attribute__((address_space(3))) u32 lds_u32_t;
+typedef u32 f4_v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f4_v4u lds_u128_t;
+__device__ __forceinline__ u32 lds_r32(u32 a) { return *(const lds_u32_t*)(uintptr_t)a; }
+__device__ __forceinline__ u32 lds_r16(u32 a) { return (u32)*(const lds_u16_t*)(uintptr_t)a; }
+__device__ __forceinline__ u32 lds_r8(u32 a) { return (u32)*(const lds_u8_t*)(uintptr_t)a; }
+__device__ __forceinline__ void lds_w8(u32 a, u32 v) { *(lds_u8_t*)(uintptr_t)a = (unsigned char)v; }
+__device__ __forceinline__ void lds_w16(u32 a, u32 v) { *(lds_u16_t*)(uintptr_t)a = (unsigned short)v; }
+__device__ __forceinline__ void lds_w128(u32 a, uint4 v) { *(lds_u128_t*)(uintptr_t)a = f4_v4u{v.x, v.y, v.z, v.w}; }
+
+// exact score of two pixels; oa / ob = LDS addresses of the top-left corners (x-3, y-3) of their 7x7 windows
+template <int P>
+__device__ __forceinline__ ss2 fast_score16x2_tl(u32 oa, u32 ob, int prt) {
+    const int p = P > 0 ? P : prt;
+#define F2(row, o) us2{(u16)lds_r8(oa + (row) * p + (o)), (u16)lds_r8(ob + (row) * p + (o))}
+    us2 r[16];
+    r[0] = F2(6, 3);   r[1] = F2(6, 4);   r[2] = F2(5, 5);   r[3] = F2(4, 6);
+    r[4] = F2(3, 6);   r[5] = F2(2, 6);   r[6] = F2(1, 5);   r[7] = F2(0, 4);
+    r[8] = F2(0, 3);   r[9] = F2(0, 2);   r[10] = F2(1, 1);  r[11] = F2(2, 0);
+    r[12] = F2(3, 0);  r[13] = F2(4, 0);  r[14] = F2(5, 1);  r[15] = F2(6, 2);
+    const us2 v = F2(3, 3);
+#undef F2
+    us2 m2[8], M2[8], m4[8], M4[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { m2[j] = pkmin(r[2 * j], r[2 * j + 1]); M2[j] = pkmax(r[2 * j], r[2 * j + 1]); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { m4[j] = pkmin(m2[j], m2[(j + 1) & 7]); M4[j] = pkmax(M2[j], M2[(j + 1) & 7]); }
+    us2 bmax = us2{0, 0}, amin = us2{255, 255};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const us2 a = r[(2 * j + 15) & 15], c = r[(2 * j + 8) & 15];
+        bmax = pkmax(bmax, pkmin(pkmin(m4[j], m4[(j + 2) & 7]), pkmax(a, c)));
+        amin = pkmin(amin, pkmax(pkmax(M4[j], M4[(j + 2) & 7]), pkmin(a, c)));
+    }
+    const ss2 d1 = __builtin_bit_cast(ss2, v - amin), d2 = __builtin_bit_cast(ss2, bmax - v);   // |.| <= 255: exact as signed 16-bit
+    return __builtin_elementwise_max(d1, d2) - ss2{1, 1};
+}
+
+template <int PITCH>
+__global__ __launch_bounds__(F3_NT) void k_fast4(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
+                                                 const CellAux* __restrict__ aux, const F4Item* __restrict__ items,
+                                                 const StripInfo* __restrict__ strips,
+                                                 u32* candCnt, u32* candEnt, int* err, int tileBytes, int qcap,
+                                                 u32* ovf, u32* ovfList) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char f3smem[];
+    const u32 imgA = (u32)(uintptr_t)(lds_u8_t*)f3smem;                  // LDS address of the image tile (wave-uniform)
+    const u32 scD = (u32)tileBytes;                                       // score tile behind the image tile, same indexing
+    StripInfo st = strips[gridDim.x - 1 - (F3_XCD ? xcd_task(blockIdx.x, gridDim.x) : blockIdx.x)];   // coarser (denser, slower) strips of the group first: a lighter tail
+    st.level = (short)__builtin_amdgcn_readfirstlane(st.level);
+    const int frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);              // wave-uniform: per-cell metadata comes through the scalar cache
+    const u32 qA = imgA + 2u * (u32)tileBytes + (u32)(wv * qcap) * 2u;    // this wave's queue (u16 entries)
+    const int Pb = PITCH > 0 ? PITCH : (int)st.lp, H = st.h;              // tile pitch in bytes
+    int sp;
+    const u8* src = level_ptr(g, l0, l0pitch, pyr, frame, st.level, &sp);
+    const LevelDesc& L = g.lv[st.level];
+    {   // tile load: 32 lanes x 16 B per row, 8 rows per pass; six passes in flight (one memory round trip).  Rows and columns are
+        // CLAMPED into the level instead of predicated: a column at or right of the image's 16-byte-rounded width is only ever
+        // read by lanes whose pixels are masked out (valid pixels end 13 columns left of the image edge), a row >= H is not stored.
+        const int cpr = Pb >> 4;
+        const int rowLimit = min((L.w + 15) & ~15, sp);
+        const int ck = tid & 31;
+        const int gx = min(st.xal + ck * 16, rowLimit - 16);
+        const bool colOk = ck < cpr;
+        const int RP = F3_NT / 32;
+        const int r0 = tid >> 5;
+        uint4 v[6];
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            const int r = min(r0 + p * RP, H - 1);
+            v[p] = gload128u(src, mad24((u32)(st.y0 + r), (u32)sp, (u32)gx));   // (written as __mul24 + add the compiler picks the 64-bit multiply-add)
+        }
+        const u32 lo = imgA + (u32)(r0 * Pb + ck * 16);
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            const int r = r0 + p * RP;
+            if (colOk && r < H) {
+                lds_w128(lo + (u32)(p * RP) * (u32)Pb, v[p]);
+                lds_w128(lo + scD + (u32)(p * RP) * (u32)Pb, make_uint4(0, 0, 0, 0));
+            }
+        }
+        for (int r = r0 + 6 * RP; r < H; r += RP) {                       // taller cells (coarse levels, tiny images)
+            if (colOk) {
+                const uint4 t = gload128u(src, (u32)(__mul24(st.y0 + r, sp) + gx));
+                lds_w128(imgA + (u32)(r * Pb + ck * 16), t);
+                lds_w128(imgA + scD + (u32)(r * Pb + ck * 16), make_uint4(0, 0, 0, 0));
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const u32 laneOff = (u32)lane * 8u;
+    for (int c = wv; c < st.ncell; c += F3_NT / 64) {
+        const CellAux ax = aux[st.cell0 + c];
+        const int nit = ax.nit;
+        const u32 cbase = imgA + ax.base;                                 // LDS address of (row 0, xs 0)
+        int n3 = 0;
+        bool ovfl = false;                                                // survivors of the quick reject exceed the queue
+        if (nit > 0) {
+            const F4Item* tab = items + ax.tab;
+            // window corner of the lane's reads: 3 rows up, 4 bytes left of its 8 pixels (all offsets below are >= 0)
+            const u32 qbase = cbase - (u32)(3 * Pb + 4);
+            for (int pass = 0; pass < 2; ++pass) {
+                const int t = pass == 0 ? g.iniTh : g.minTh;
+                if (pass == 1 && g.minTh >= g.iniTh) break;               // a higher retry threshold cannot add corners
+                const us2 t2 = as_us2((u32)t * 0x00010001u);
+                // ---- quick reject + compaction
+                int n1 = 0;
+                // Item loads are inline asm.  A compiler-visible load of the NEXT item gets sunk below the overflow test (it then
+                // completes right behind the short append loop, exposed), and one of the first item makes the compiler wait for
+                // vmcnt(0) inside the loop (the counter is in order), i.e. for the prefetch.  The asm load writes nx / ny while the
+                // iteration runs; the statement at the bottom waits and only then reads them (its inputs ARE the load's registers:
+                // no tied operand, so no copy can be placed in front of the wait -- checked in the ISA).
+                uint2 cur;                                                 // .x = mask, .y = offq of the current item
+                asm volatile("global_load_dwordx2 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=&v"(cur) : "v"(laneOff), "s"(tab) : "memory");
+                for (int it = 0; it < nit; ++it) {
+                    uint2 nxt;
+                    {
+                        const F4Item* np = tab + (size_t)min(it + 1, nit - 1) * 64;
+                        asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(nxt) : "v"(laneOff), "s"(np) : "memory");
+                    }
+                    u32 m;
+                    {
+                        const u32 o = qbase + (cur.y & 0xFFFFu);
+                        const u32 U0 = lds_r32(o + 4), U1 = lds_r32(o + 8);
+                        const u32 A = lds_r32(o + 3 * Pb), B0 = lds_r32(o + 3 * Pb + 4), B1 = lds_r32(o + 3 * Pb + 8), Cw = lds_r32(o + 3 * Pb + 12);
+                        const u32 D0 = lds_r32(o + 6 * Pb + 4), D1 = lds_r32(o + 6 * Pb + 8);
+                        // even / odd bytes of every word as 16-bit pairs: e* = pixels (0,2) of the word, o* = pixels (1,3)
+                        const u32 SE = 0x0c020c00u, SO = 0x0c030c01u;
+#define F3_E(w) as_us2(__builtin_amdgcn_perm(0, (w), SE))
+#define F3_O(w) as_us2(__builtin_amdgcn_perm(0, (w), SO))
+#define F3_AL(hi, lo) as_us2(__builtin_amdgcn_alignbyte(as_u32(hi), as_u32(lo), 2))   /* (lo.hi16, hi.lo16) */
+                        const us2 eA = F3_E(A), oA = F3_O(A), eB0 = F3_E(B0), oB0 = F3_O(B0), eB1 = F3_E(B1),
+                                  oB1 = F3_O(B1), eC = F3_E(Cw), oC = F3_O(Cw);
+                        // pixel groups of the lane's 8: G0 = (0,2) G1 = (1,3) G2 = (4,6) G3 = (5,7); left = x-3, right = x+3
+                        const us2 vv[4] = {eB0, oB0, eB1, oB1};
+                        const us2 uu[4] = {F3_E(U0), F3_O(U0), F3_E(U1), F3_O(U1)};
+                        const us2 dd[4] = {F3_E(D0), F3_O(D0), F3_E(D1), F3_O(D1)};
+                        const us2 ll[4] = {oA, F3_AL(eB0, eA), oB0, F3_AL(eB1, eB0)};
+                        const us2 rr4[4] = {F3_AL(oB1, oB0), eB1, F3_AL(oC, oB1), eC};
+#undef F3_E
+#undef F3_O
+#undef F3_AL
+                        u32 sg[4];
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const us2 X = pkmax(pkmin(uu[gq], dd[gq]), pkmin(ll[gq], rr4[gq]));
+                            const us2 Y = pkmin(pkmax(uu[gq], dd[gq]), pkmax(ll[gq], rr4[gq]));
+                            // survivor <=> v - X > t or Y - v > t <=> t - max(v - X, Y - v) < 0 (signed halves, |.| <= 255): sign bit of a half
+                            sg[gq] = as_u32(__builtin_bit_cast(us2, __builtin_bit_cast(ss2, t2) - __builtin_elementwise_max(__builtin_bit_cast(ss2, vv[gq] - X), __builtin_bit_cast(ss2, Y - vv[gq]))));
+                        }
+                        const u32 Me = __builtin_amdgcn_perm(sg[2], sg[0], 0x07050301u);   // high bytes of px 0,2,4,6
+                        const u32 Mo = __builtin_amdgcn_perm(sg[3], sg[1], 0x07050301u);   // px 1,3,5,7
+                        m = (((Me >> 4) & 0x08080808u) | (Mo & 0x80808080u)) & cur.x;
+                    }
+                    // wave-inclusive prefix of popcount(m) (0..8) by a DPP scan, then each lane appends its own survivors
+                    const int cn = __popc(m);
+                    int sc_;
+                    asm volatile("s_nop 1\n\t"
+                                 "v_add_u32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                                 "v_add_u32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                                 "v_add_u32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                                 "s_nop 1\n\t"
+                                 "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+                                 "s_nop 1\n\t"
+                                 "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+                                 "s_nop 1\n\t"
+                                 "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                                 "s_nop 1\n\t"
+                                 "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                                 "s_nop 0"
+                                 : "=&v"(sc_) : "v"(cn));
+                    const int tot = __builtin_amdgcn_readlane(sc_, 63);
+                    if (n1 + tot > qcap) { ovfl = true; break; }             // wave-uniform; the cell goes to k_fast_fix
+                    u32 qa = qA + (u32)(n1 + sc_ - cn) * 2u;
+                    const u32 eb = cur.y >> 16;
+                    u32 mm = m;
+                    while (mm) {
+                        lds_w16(qa, eb | (u32)__builtin_ctz(mm));
+                        qa += 2;
+                        mm &= mm - 1;
+                    }
+                    n1 += tot;
+                    asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(cur.x), "=&v"(cur.y) : "v"(nxt.x), "v"(nxt.y) : "memory");
+                }
+                if (ovfl) break;
+                // ---- exact score, two survivors per lane (entries 2*lane and 2*lane+1 keep the queue order); keep S >= t in place
+                int n2 = 0;
+                const u32 wbase = cbase - (u32)(3 * Pb + 3);                 // (row 0, xs 0) -> top-left corner of its 7x7 window
+                for (int e0 = 0; e0 < n1; e0 += 128) {
+                    const int eA = e0 + 2 * lane, eB = eA + 1;
+                    const u32 both = lds_r32(qA + 2u * (u32)min(eA, (n1 - 1) & ~1));      // entries eA, eB in one aligned 32-bit read
+                    const u32 xa = __builtin_amdgcn_ubfe(both, 2, 7), ya = __builtin_amdgcn_ubfe(both, 9, 7);
+                    const u32 xb = __builtin_amdgcn_ubfe(both, 18, 7), yb = both >> 25;
+                    const u32 oa = ya * (u32)Pb + xa + wbase;
+                    const u32 ob0 = yb * (u32)Pb + xb + wbase;
+                    const u32 ob = eB < n1 ? ob0 : oa;                       // odd tail: score A twice, B is masked out
+                    const ss2 sv = fast_score16x2_tl<PITCH>(oa, ob, Pb);
+                    const bool fA = eA < n1 && sv.x >= t, fB = eB < n1 && sv.y >= t;
+                    if (fA) lds_w8(oa + scD + 3 * Pb + 3, (u32)sv.x);
+                    if (fB) lds_w8(ob + scD + 3 * Pb + 3, (u32)sv.y);
+                    const unsigned long long balA = __ballot(fA), balB = __ballot(fB);
+                    const u32 posA = qA + 2u * (u32)(n2 + __popcll(balA & lt) + __popcll(balB & lt));
+                    if (fA) lds_w16(posA, both);
+                    if (fB) lds_w16(posA + (fA ? 2u : 0u), both >> 16);
+                    n2 += __popcll(balA) + __popcll(balB);
+                }
+                // ---- strict 3x3 maxima inside the cell window (in place)
+                n3 = 0;
+                const u32 sbase = cbase + scD - (u32)(Pb + 1);               // (row 0, xs 0) -> its upper-left neighbour in the score tile
+                for (int e0 = 0; e0 < n2; e0 += 64) {
+                    const int e = e0 + lane;
+                    bool keep = false;
+                    u32 pq = 0;
+                    if (e < n2) {
+                        pq = lds_r16(qA + 2u * (u32)e);
+                        const u32 xs = __builtin_amdgcn_ubfe(pq, 2, 7);
+                        const u32 o = (pq >> 9) * (u32)Pb + xs + sbase;
+                        // branch-free: all eight neighbours are read (the tile has a halo; a neighbour column outside the cell's
+                        // window may hold another cell's score, possibly mid-write -- it is masked to 0, never used)
+                        const int s = (int)lds_r8(o + Pb + 1);
+                        const int ml = max(max((int)lds_r8(o + Pb), (int)lds_r8(o)), (int)lds_r8(o + 2 * Pb));
+                        const int mr = max(max((int)lds_r8(o + Pb + 2), (int)lds_r8(o + 2)), (int)lds_r8(o + 2 * Pb + 2));
+                        const int mv = max((int)lds_r8(o + 1), (int)lds_r8(o + 2 * Pb + 1));
+                        keep = s > max(mv, max(xs > (u32)ax.xlo ? ml : 0, xs < (u32)ax.xhi ? mr : 0));
+                    }
+                    const unsigned long long bal = __ballot(keep);
+                    if (keep) lds_w16(qA + 2u * (u32)(n3 + __popcll(bal & lt)), pq);
+                    n3 += __popcll(bal);
+                }
+                if (n3 > 0) break;
+            }
+        }
+        if (ovfl) {
+            if (lane == 0) ovfList[atomicAdd(&ovf[0], 1u)] = (u32)frame * (u32)g.totalCells + (u32)(st.cell0 + c);
+            continue;
+        }
+        // ---- packed store.  The queue is row-major by construction: the quick reject appends iteration by iteration
+        // (items in (row, column) order), lanes in item order through the wave prefix, pixels of a lane in ascending x; the two
+        // in-place compactions are stable.  cv::FAST emits in the same order, so entry e is candidate e of the cell.
+        u32* out = candEnt + (size_t)frame * g.totalSlots + ax.slot;
+        for (int e0 = 0; e0 < n3; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < n3) {
+                const u32 my = lds_r16(qA + 2u * (u32)e);
+                const u32 xs = __builtin_amdgcn_ubfe(my, 2, 7), row = my >> 9;
+                const u32 s = lds_r8(cbase + scD + row * (u32)Pb + xs);
+                if (e < L.slotCap)
+                    out[e] = (u32)((int)ax.outx + (int)xs) | ((u32)((int)ax.outy + (int)row) << 12) | (s << 24);
+                else atomicExch(err, 1);
+            }
+        }
+        if (lane == 0) candCnt[(size_t)frame * g.totalCells + ax.cnt] = (u32)n3;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_quadtree: ORBextractor::DistributeOctTree for one (level, frame) per workgroup.
 // Keypoint-side work (quadrant histograms, re-labelling, per-node arg-max) is parallel over candidates;
 // the order-defining list surgery (push_front / erase / early break at N) is replayed by lane 0 on a
