@@ -450,6 +450,7 @@ static int build_geometry(orbx* o, int w, int h) {
         if (!all.empty()) HIPCHK(hipMemcpy(o->dRzTasks, all.data(), all.size() * sizeof(RzTask), hipMemcpyHostToDevice));
     }
     if (ensure(&o->dCandCnt, &o->capCandCnt, (size_t)g.totalCells * B)) return ORBX_E_HIP;
+    HIPCHK(hipMemset(o->dCandCnt, 0, sizeof(u32) * (size_t)g.totalCells * B));   // a cell no kernel has written yet is an EMPTY cell, not whatever the allocation held
     { size_t c2 = 0; if (o->dKpNode) (void)hipFree(o->dKpNode); o->dKpNode = nullptr; if (ensure(&o->dKpNode, &c2, (size_t)g.totalSlots * B)) return ORBX_E_HIP; }
     if (ensure(&o->dCandEnt, &o->capCandEnt, (size_t)g.totalSlots * B)) return ORBX_E_HIP;
     { size_t c2 = 0; if (o->dDense) (void)hipFree(o->dDense); o->dDense = nullptr; if (ensure(&o->dDense, &c2, (size_t)g.totalSlots * B)) return ORBX_E_HIP; }

@@ -759,6 +759,221 @@ __device__ __forceinline__ ss2 fast_score16x2_tl(u32 oa, u32 ob, int prt) {
     return __builtin_elementwise_max(d1, d2) - ss2{1, 1};
 }
 
+// number of set bits of a wave mask below this lane (v_mbcnt_lo + v_mbcnt_hi on the scalar mask: no per-lane "lanes below" constant)
+__device__ __forceinline__ int f4_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+}
+
+// One FAST cell by one wave, in three phases.
+struct F4Ctx {                                              // wave-uniform context of a cell
+    u32 imgA, scD, qA, cbase;                               // LDS addresses: image tile, score tile distance, the wave's queue, (row 0, xs 0)
+    int Pb, qcap, lane;
+};
+
+// quick reject at threshold t: survivors appended to the wave's queue in row-major order; returns their number, -1 if the queue overflowed
+template <int PITCH>
+__device__ __forceinline__ int f4_quick(const F4Ctx& cx, const CellAux& ax, const F4Item* __restrict__ items, const int t) {
+    const int Pb = PITCH > 0 ? PITCH : cx.Pb, qcap = cx.qcap;
+    const u32 qA = cx.qA;
+    const u32 laneOff = (u32)cx.lane * 8u;
+    const int nit = ax.nit;
+    const F4Item* tab = items + ax.tab;
+    // window corner of the lane's reads: 3 rows up, 4 bytes left of its 8 pixels (all offsets below are >= 0)
+    const u32 qbase = cx.cbase - (u32)(3 * Pb + 4);
+    const us2 t2 = as_us2((u32)t * 0x00010001u);
+    int n1 = 0;
+    // Item loads are inline asm.  A compiler-visible load of the NEXT item gets sunk below the overflow test (it then
+    // completes right behind the short append loop, exposed), and one of the first item makes the compiler wait for
+    // vmcnt(0) inside the loop (the counter is in order), i.e. for the prefetch.  The asm load writes nx / ny while the
+    // iteration runs; the statement at the bottom waits and only then reads them (its inputs ARE the load's registers:
+    // no tied operand, so no copy can be placed in front of the wait -- checked in the ISA).
+    uint2 cur;                                                 // .x = mask, .y = offq of the current item
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=&v"(cur) : "v"(laneOff), "s"(tab) : "memory");
+    for (int it = 0; it < nit; ++it) {
+        uint2 nxt;
+        {
+            const F4Item* np = tab + (size_t)min(it + 1, nit - 1) * 64;
+            asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(nxt) : "v"(laneOff), "s"(np) : "memory");
+        }
+        u32 m;
+        {
+            const u32 o = qbase + (cur.y & 0xFFFFu);
+            const u32 U0 = lds_r32(o + 4), U1 = lds_r32(o + 8);
+            const u32 A = lds_r32(o + 3 * Pb), B0 = lds_r32(o + 3 * Pb + 4), B1 = lds_r32(o + 3 * Pb + 8), Cw = lds_r32(o + 3 * Pb + 12);
+            const u32 D0 = lds_r32(o + 6 * Pb + 4), D1 = lds_r32(o + 6 * Pb + 8);
+            // even / odd bytes of every word as 16-bit pairs: e* = pixels (0,2) of the word, o* = pixels (1,3)
+            const u32 SE = 0x0c020c00u, SO = 0x0c030c01u;
+#define F3_E(w) as_us2(__builtin_amdgcn_perm(0, (w), SE))
+#define F3_O(w) as_us2(__builtin_amdgcn_perm(0, (w), SO))
+#define F3_AL(hi, lo) as_us2(__builtin_amdgcn_alignbyte(as_u32(hi), as_u32(lo), 2))   /* (lo.hi16, hi.lo16) */
+            const us2 eA = F3_E(A), oA = F3_O(A), eB0 = F3_E(B0), oB0 = F3_O(B0), eB1 = F3_E(B1),
+                      oB1 = F3_O(B1), eC = F3_E(Cw), oC = F3_O(Cw);
+            // pixel groups of the lane's 8: G0 = (0,2) G1 = (1,3) G2 = (4,6) G3 = (5,7); left = x-3, right = x+3
+            const us2 vv[4] = {eB0, oB0, eB1, oB1};
+            const us2 uu[4] = {F3_E(U0), F3_O(U0), F3_E(U1), F3_O(U1)};
+            const us2 dd[4] = {F3_E(D0), F3_O(D0), F3_E(D1), F3_O(D1)};
+            const us2 ll[4] = {oA, F3_AL(eB0, eA), oB0, F3_AL(eB1, eB0)};
+            const us2 rr4[4] = {F3_AL(oB1, oB0), eB1, F3_AL(oC, oB1), eC};
+#undef F3_E
+#undef F3_O
+#undef F3_AL
+            u32 sg[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const us2 X = pkmax(pkmin(uu[gq], dd[gq]), pkmin(ll[gq], rr4[gq]));
+                const us2 Y = pkmin(pkmax(uu[gq], dd[gq]), pkmax(ll[gq], rr4[gq]));
+                // survivor <=> v - X > t or Y - v > t <=> t - max(v - X, Y - v) < 0 (signed halves, |.| <= 255): sign bit of a half
+                sg[gq] = as_u32(__builtin_bit_cast(us2, __builtin_bit_cast(ss2, t2) - __builtin_elementwise_max(__builtin_bit_cast(ss2, vv[gq] - X), __builtin_bit_cast(ss2, Y - vv[gq]))));
+            }
+            const u32 Me = __builtin_amdgcn_perm(sg[2], sg[0], 0x07050301u);   // high bytes of px 0,2,4,6
+            const u32 Mo = __builtin_amdgcn_perm(sg[3], sg[1], 0x07050301u);   // px 1,3,5,7
+            m = (((Me >> 4) & 0x08080808u) | (Mo & 0x80808080u)) & cur.x;
+        }
+        // wave-inclusive prefix of popcount(m) (0..8) by a DPP scan, then each lane appends its own survivors
+        const int cn = __popc(m);
+        int sc_;
+        asm volatile("s_nop 1\n\t"
+                     "v_add_u32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_add_u32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_add_u32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "s_nop 1\n\t"
+                     "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+                     "s_nop 1\n\t"
+                     "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+                     "s_nop 1\n\t"
+                     "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                     "s_nop 0"
+                     : "=&v"(sc_) : "v"(cn));
+#ifdef F4_ABL_NOAPPEND
+        const int tot = (m == 0x12345u) ? 1 : 0;
+#else
+        const int tot = __builtin_amdgcn_readlane(sc_, 63);
+#endif
+        if (n1 + tot > qcap) {                                   // wave-uniform; the cell goes to k_fast_fix
+            // the prefetched item must LAND before its registers die: the compiler is free to reuse them at once, and a load that
+            // arrives later would overwrite whatever they hold by then
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt.x), "+v"(nxt.y) : : "memory");
+            return -1;
+        }
+        u32 qa = qA + (u32)(n1 + sc_ - cn) * 2u;
+        const u32 eb = cur.y >> 16;
+        u32 mm = m;
+        while (mm) {
+            lds_w16(qa, eb | (u32)__builtin_ctz(mm));
+            qa += 2;
+            mm &= mm - 1;
+        }
+        n1 += tot;
+        asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(cur.x), "=&v"(cur.y) : "v"(nxt.x), "v"(nxt.y) : "memory");
+    }
+    return n1;
+}
+
+// exact score of the n1 queued survivors at threshold t, then strict 3x3 maxima inside the cell window; both compact the queue in place.
+// Returns the number of keypoints left in the queue.
+template <int PITCH>
+__device__ __forceinline__ int f4_score_nms(const F4Ctx& cx, const CellAux& ax, const int t, const int n1) {
+    const int Pb = PITCH > 0 ? PITCH : cx.Pb, lane = cx.lane;
+    const u32 qA = cx.qA, scD = cx.scD, cbase = cx.cbase;
+#if defined(F4_ABL_NOSCORE) || defined(F4_ABL_NOAPPEND)
+    if (n1 < 60000) return 0;
+#endif
+    // ---- exact score, two survivors per lane (entries 2*lane and 2*lane+1 keep the queue order); keep S >= t in place
+    int n2 = 0;
+    const u32 wbase = cbase - (u32)(3 * Pb + 3);                 // (row 0, xs 0) -> top-left corner of its 7x7 window
+    for (int e0 = 0; e0 < n1; e0 += 128) {
+        const int eA = e0 + 2 * lane, eB = eA + 1;
+        const u32 both = lds_r32(qA + 2u * (u32)min(eA, (n1 - 1) & ~1));      // entries eA, eB in one aligned 32-bit read
+        const u32 xa = __builtin_amdgcn_ubfe(both, 2, 7), ya = __builtin_amdgcn_ubfe(both, 9, 7);
+        const u32 xb = __builtin_amdgcn_ubfe(both, 18, 7), yb = both >> 25;
+        const u32 oa = ya * (u32)Pb + xa + wbase;
+        const u32 ob0 = yb * (u32)Pb + xb + wbase;
+        const u32 ob = eB < n1 ? ob0 : oa;                       // odd tail: score A twice, B is masked out
+        const ss2 sv = fast_score16x2_tl<PITCH>(oa, ob, Pb);
+        const bool fA = eA < n1 && sv.x >= t, fB = eB < n1 && sv.y >= t;
+        if (fA) lds_w8(oa + scD + 3 * Pb + 3, (u32)sv.x);
+        if (fB) lds_w8(ob + scD + 3 * Pb + 3, (u32)sv.y);
+        const unsigned long long balA = __ballot(fA), balB = __ballot(fB);
+        const u32 posA = qA + 2u * (u32)(n2 + f4_below(balA) + f4_below(balB));
+        if (fA) lds_w16(posA, both);
+        if (fB) lds_w16(posA + (fA ? 2u : 0u), both >> 16);
+        n2 += __popcll(balA) + __popcll(balB);
+    }
+#ifdef F4_ABL_NONMS
+    if (n2 < 60000) return 0;
+#endif
+    // ---- strict 3x3 maxima inside the cell window (in place)
+    int n3 = 0;
+    const u32 sbase = cbase + scD - (u32)(Pb + 1);               // (row 0, xs 0) -> its upper-left neighbour in the score tile
+    for (int e0 = 0; e0 < n2; e0 += 64) {
+        const int e = e0 + lane;
+        bool keep = false;
+        u32 pq = 0;
+        if (e < n2) {
+            pq = lds_r16(qA + 2u * (u32)e);
+            const u32 xs = __builtin_amdgcn_ubfe(pq, 2, 7);
+            const u32 o = (pq >> 9) * (u32)Pb + xs + sbase;
+            // branch-free: all eight neighbours are read (the tile has a halo; a neighbour column outside the cell's
+            // window may hold another cell's score, possibly mid-write -- it is masked to 0, never used)
+            const int s = (int)lds_r8(o + Pb + 1);
+            const int ml = max(max((int)lds_r8(o + Pb), (int)lds_r8(o)), (int)lds_r8(o + 2 * Pb));
+            const int mr = max(max((int)lds_r8(o + Pb + 2), (int)lds_r8(o + 2)), (int)lds_r8(o + 2 * Pb + 2));
+            const int mv = max((int)lds_r8(o + 1), (int)lds_r8(o + 2 * Pb + 1));
+            keep = s > max(mv, max(xs > (u32)ax.xlo ? ml : 0, xs < (u32)ax.xhi ? mr : 0));
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (keep) lds_w16(qA + 2u * (u32)(n3 + f4_below(bal)), pq);
+        n3 += __popcll(bal);
+    }
+    return n3;
+}
+
+// packed store of the n3 keypoints in the queue + the cell's count
+template <int PITCH>
+__device__ __forceinline__ void f4_store(const Geom& g, const F4Ctx& cx, const CellAux& ax, const int n3, const int slotCap, const int frame,
+                                         u32* candCnt, u32* candEnt, int* err) {
+    const int Pb = PITCH > 0 ? PITCH : cx.Pb, lane = cx.lane;
+    const u32 qA = cx.qA, scD = cx.scD, cbase = cx.cbase;
+    // ---- packed store.  The queue is row-major by construction: the quick reject appends iteration by iteration
+    // (items in (row, column) order), lanes in item order through the wave prefix, pixels of a lane in ascending x; the two
+    // in-place compactions are stable.  cv::FAST emits in the same order, so entry e is candidate e of the cell.
+    u32* out = candEnt + (size_t)frame * g.totalSlots + ax.slot;
+    for (int e0 = 0; e0 < n3; e0 += 64) {
+        const int e = e0 + lane;
+        if (e < n3) {
+            const u32 my = lds_r16(qA + 2u * (u32)e);
+            const u32 xs = __builtin_amdgcn_ubfe(my, 2, 7), row = my >> 9;
+            const u32 s = lds_r8(cbase + scD + row * (u32)Pb + xs);
+            if (e < slotCap)
+                out[e] = (u32)((int)ax.outx + (int)xs) | ((u32)((int)ax.outy + (int)row) << 12) | (s << 24);
+            else atomicExch(err, 1);
+        }
+    }
+    if (lane == 0) candCnt[(size_t)frame * g.totalCells + ax.cnt] = (u32)n3;
+}
+
+// cv::FAST at iniTh and, only if that leaves the cell empty after non-max suppression, at minTh (ORBextractor.cc:1112-1125);
+// `n1` = result of the first quick pass (already run by the caller)
+template <int PITCH>
+__device__ __forceinline__ void f4_finish(const Geom& g, const F4Ctx& cx, const CellAux& ax, const F4Item* __restrict__ items, int n1, const int slotCap,
+                                          const int frame, const int cellIdx, u32* candCnt, u32* candEnt, int* err, u32* ovf, u32* ovfList) {
+    int n3 = 0;
+    if (n1 > 0) n3 = f4_score_nms<PITCH>(cx, ax, g.iniTh, n1);
+#if !defined(F4_ABL_NOSCORE) && !defined(F4_ABL_NOAPPEND) && !defined(F4_ABL_NONMS)
+    if (n1 >= 0 && n3 == 0 && ax.nit > 0 && g.minTh < g.iniTh) {       // (a higher retry threshold cannot add corners)
+        n1 = f4_quick<PITCH>(cx, ax, items, g.minTh);
+        if (n1 > 0) n3 = f4_score_nms<PITCH>(cx, ax, g.minTh, n1);
+    }
+#endif
+    if (n1 < 0) {
+        if (cx.lane == 0) ovfList[atomicAdd(&ovf[0], 1u)] = (u32)frame * (u32)g.totalCells + (u32)cellIdx;
+        return;
+    }
+    f4_store<PITCH>(g, cx, ax, n3, slotCap, frame, candCnt, candEnt, err);
+}
+
 template <int PITCH>
 __global__ __launch_bounds__(F3_NT) void k_fast4(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
                                                  const CellAux* __restrict__ aux, const F4Item* __restrict__ items,
@@ -791,7 +1006,11 @@ __global__ __launch_bounds__(F3_NT) void k_fast4(Geom g, const u8* const* l0, in
 #pragma unroll
         for (int p = 0; p < 6; ++p) {
             const int r = min(r0 + p * RP, H - 1);
+#ifdef F4_ABL_NOLOAD
+            v[p] = make_uint4(r, gx, sp, 0);
+#else
             v[p] = gload128u(src, mad24((u32)(st.y0 + r), (u32)sp, (u32)gx));   // (written as __mul24 + add the compiler picks the 64-bit multiply-add)
+#endif
         }
         const u32 lo = imgA + (u32)(r0 * Pb + ck * 16);
 #pragma unroll
@@ -811,169 +1030,15 @@ __global__ __launch_bounds__(F3_NT) void k_fast4(Geom g, const u8* const* l0, in
         }
     }
     __syncthreads();
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const u32 laneOff = (u32)lane * 8u;
     for (int c = wv; c < st.ncell; c += F3_NT / 64) {
         const CellAux ax = aux[st.cell0 + c];
-        const int nit = ax.nit;
-        const u32 cbase = imgA + ax.base;                                 // LDS address of (row 0, xs 0)
-        int n3 = 0;
-        bool ovfl = false;                                                // survivors of the quick reject exceed the queue
-        if (nit > 0) {
-            const F4Item* tab = items + ax.tab;
-            // window corner of the lane's reads: 3 rows up, 4 bytes left of its 8 pixels (all offsets below are >= 0)
-            const u32 qbase = cbase - (u32)(3 * Pb + 4);
-            for (int pass = 0; pass < 2; ++pass) {
-                const int t = pass == 0 ? g.iniTh : g.minTh;
-                if (pass == 1 && g.minTh >= g.iniTh) break;               // a higher retry threshold cannot add corners
-                const us2 t2 = as_us2((u32)t * 0x00010001u);
-                // ---- quick reject + compaction
-                int n1 = 0;
-                // Item loads are inline asm.  A compiler-visible load of the NEXT item gets sunk below the overflow test (it then
-                // completes right behind the short append loop, exposed), and one of the first item makes the compiler wait for
-                // vmcnt(0) inside the loop (the counter is in order), i.e. for the prefetch.  The asm load writes nx / ny while the
-                // iteration runs; the statement at the bottom waits and only then reads them (its inputs ARE the load's registers:
-                // no tied operand, so no copy can be placed in front of the wait -- checked in the ISA).
-                uint2 cur;                                                 // .x = mask, .y = offq of the current item
-                asm volatile("global_load_dwordx2 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=&v"(cur) : "v"(laneOff), "s"(tab) : "memory");
-                for (int it = 0; it < nit; ++it) {
-                    uint2 nxt;
-                    {
-                        const F4Item* np = tab + (size_t)min(it + 1, nit - 1) * 64;
-                        asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(nxt) : "v"(laneOff), "s"(np) : "memory");
-                    }
-                    u32 m;
-                    {
-                        const u32 o = qbase + (cur.y & 0xFFFFu);
-                        const u32 U0 = lds_r32(o + 4), U1 = lds_r32(o + 8);
-                        const u32 A = lds_r32(o + 3 * Pb), B0 = lds_r32(o + 3 * Pb + 4), B1 = lds_r32(o + 3 * Pb + 8), Cw = lds_r32(o + 3 * Pb + 12);
-                        const u32 D0 = lds_r32(o + 6 * Pb + 4), D1 = lds_r32(o + 6 * Pb + 8);
-                        // even / odd bytes of every word as 16-bit pairs: e* = pixels (0,2) of the word, o* = pixels (1,3)
-                        const u32 SE = 0x0c020c00u, SO = 0x0c030c01u;
-#define F3_E(w) as_us2(__builtin_amdgcn_perm(0, (w), SE))
-#define F3_O(w) as_us2(__builtin_amdgcn_perm(0, (w), SO))
-#define F3_AL(hi, lo) as_us2(__builtin_amdgcn_alignbyte(as_u32(hi), as_u32(lo), 2))   /* (lo.hi16, hi.lo16) */
-                        const us2 eA = F3_E(A), oA = F3_O(A), eB0 = F3_E(B0), oB0 = F3_O(B0), eB1 = F3_E(B1),
-                                  oB1 = F3_O(B1), eC = F3_E(Cw), oC = F3_O(Cw);
-                        // pixel groups of the lane's 8: G0 = (0,2) G1 = (1,3) G2 = (4,6) G3 = (5,7); left = x-3, right = x+3
-                        const us2 vv[4] = {eB0, oB0, eB1, oB1};
-                        const us2 uu[4] = {F3_E(U0), F3_O(U0), F3_E(U1), F3_O(U1)};
-                        const us2 dd[4] = {F3_E(D0), F3_O(D0), F3_E(D1), F3_O(D1)};
-                        const us2 ll[4] = {oA, F3_AL(eB0, eA), oB0, F3_AL(eB1, eB0)};
-                        const us2 rr4[4] = {F3_AL(oB1, oB0), eB1, F3_AL(oC, oB1), eC};
-#undef F3_E
-#undef F3_O
-#undef F3_AL
-                        u32 sg[4];
-#pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) {
-                            const us2 X = pkmax(pkmin(uu[gq], dd[gq]), pkmin(ll[gq], rr4[gq]));
-                            const us2 Y = pkmin(pkmax(uu[gq], dd[gq]), pkmax(ll[gq], rr4[gq]));
-                            // survivor <=> v - X > t or Y - v > t <=> t - max(v - X, Y - v) < 0 (signed halves, |.| <= 255): sign bit of a half
-                            sg[gq] = as_u32(__builtin_bit_cast(us2, __builtin_bit_cast(ss2, t2) - __builtin_elementwise_max(__builtin_bit_cast(ss2, vv[gq] - X), __builtin_bit_cast(ss2, Y - vv[gq]))));
-                        }
-                        const u32 Me = __builtin_amdgcn_perm(sg[2], sg[0], 0x07050301u);   // high bytes of px 0,2,4,6
-                        const u32 Mo = __builtin_amdgcn_perm(sg[3], sg[1], 0x07050301u);   // px 1,3,5,7
-                        m = (((Me >> 4) & 0x08080808u) | (Mo & 0x80808080u)) & cur.x;
-                    }
-                    // wave-inclusive prefix of popcount(m) (0..8) by a DPP scan, then each lane appends its own survivors
-                    const int cn = __popc(m);
-                    int sc_;
-                    asm volatile("s_nop 1\n\t"
-                                 "v_add_u32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                                 "v_add_u32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                                 "v_add_u32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                                 "s_nop 1\n\t"
-                                 "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
-                                 "s_nop 1\n\t"
-                                 "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
-                                 "s_nop 1\n\t"
-                                 "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                                 "s_nop 1\n\t"
-                                 "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-                                 "s_nop 0"
-                                 : "=&v"(sc_) : "v"(cn));
-                    const int tot = __builtin_amdgcn_readlane(sc_, 63);
-                    if (n1 + tot > qcap) { ovfl = true; break; }             // wave-uniform; the cell goes to k_fast_fix
-                    u32 qa = qA + (u32)(n1 + sc_ - cn) * 2u;
-                    const u32 eb = cur.y >> 16;
-                    u32 mm = m;
-                    while (mm) {
-                        lds_w16(qa, eb | (u32)__builtin_ctz(mm));
-                        qa += 2;
-                        mm &= mm - 1;
-                    }
-                    n1 += tot;
-                    asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(cur.x), "=&v"(cur.y) : "v"(nxt.x), "v"(nxt.y) : "memory");
-                }
-                if (ovfl) break;
-                // ---- exact score, two survivors per lane (entries 2*lane and 2*lane+1 keep the queue order); keep S >= t in place
-                int n2 = 0;
-                const u32 wbase = cbase - (u32)(3 * Pb + 3);                 // (row 0, xs 0) -> top-left corner of its 7x7 window
-                for (int e0 = 0; e0 < n1; e0 += 128) {
-                    const int eA = e0 + 2 * lane, eB = eA + 1;
-                    const u32 both = lds_r32(qA + 2u * (u32)min(eA, (n1 - 1) & ~1));      // entries eA, eB in one aligned 32-bit read
-                    const u32 xa = __builtin_amdgcn_ubfe(both, 2, 7), ya = __builtin_amdgcn_ubfe(both, 9, 7);
-                    const u32 xb = __builtin_amdgcn_ubfe(both, 18, 7), yb = both >> 25;
-                    const u32 oa = ya * (u32)Pb + xa + wbase;
-                    const u32 ob0 = yb * (u32)Pb + xb + wbase;
-                    const u32 ob = eB < n1 ? ob0 : oa;                       // odd tail: score A twice, B is masked out
-                    const ss2 sv = fast_score16x2_tl<PITCH>(oa, ob, Pb);
-                    const bool fA = eA < n1 && sv.x >= t, fB = eB < n1 && sv.y >= t;
-                    if (fA) lds_w8(oa + scD + 3 * Pb + 3, (u32)sv.x);
-                    if (fB) lds_w8(ob + scD + 3 * Pb + 3, (u32)sv.y);
-                    const unsigned long long balA = __ballot(fA), balB = __ballot(fB);
-                    const u32 posA = qA + 2u * (u32)(n2 + __popcll(balA & lt) + __popcll(balB & lt));
-                    if (fA) lds_w16(posA, both);
-                    if (fB) lds_w16(posA + (fA ? 2u : 0u), both >> 16);
-                    n2 += __popcll(balA) + __popcll(balB);
-                }
-                // ---- strict 3x3 maxima inside the cell window (in place)
-                n3 = 0;
-                const u32 sbase = cbase + scD - (u32)(Pb + 1);               // (row 0, xs 0) -> its upper-left neighbour in the score tile
-                for (int e0 = 0; e0 < n2; e0 += 64) {
-                    const int e = e0 + lane;
-                    bool keep = false;
-                    u32 pq = 0;
-                    if (e < n2) {
-                        pq = lds_r16(qA + 2u * (u32)e);
-                        const u32 xs = __builtin_amdgcn_ubfe(pq, 2, 7);
-                        const u32 o = (pq >> 9) * (u32)Pb + xs + sbase;
-                        // branch-free: all eight neighbours are read (the tile has a halo; a neighbour column outside the cell's
-                        // window may hold another cell's score, possibly mid-write -- it is masked to 0, never used)
-                        const int s = (int)lds_r8(o + Pb + 1);
-                        const int ml = max(max((int)lds_r8(o + Pb), (int)lds_r8(o)), (int)lds_r8(o + 2 * Pb));
-                        const int mr = max(max((int)lds_r8(o + Pb + 2), (int)lds_r8(o + 2)), (int)lds_r8(o + 2 * Pb + 2));
-                        const int mv = max((int)lds_r8(o + 1), (int)lds_r8(o + 2 * Pb + 1));
-                        keep = s > max(mv, max(xs > (u32)ax.xlo ? ml : 0, xs < (u32)ax.xhi ? mr : 0));
-                    }
-                    const unsigned long long bal = __ballot(keep);
-                    if (keep) lds_w16(qA + 2u * (u32)(n3 + __popcll(bal & lt)), pq);
-                    n3 += __popcll(bal);
-                }
-                if (n3 > 0) break;
-            }
-        }
-        if (ovfl) {
-            if (lane == 0) ovfList[atomicAdd(&ovf[0], 1u)] = (u32)frame * (u32)g.totalCells + (u32)(st.cell0 + c);
-            continue;
-        }
-        // ---- packed store.  The queue is row-major by construction: the quick reject appends iteration by iteration
-        // (items in (row, column) order), lanes in item order through the wave prefix, pixels of a lane in ascending x; the two
-        // in-place compactions are stable.  cv::FAST emits in the same order, so entry e is candidate e of the cell.
-        u32* out = candEnt + (size_t)frame * g.totalSlots + ax.slot;
-        for (int e0 = 0; e0 < n3; e0 += 64) {
-            const int e = e0 + lane;
-            if (e < n3) {
-                const u32 my = lds_r16(qA + 2u * (u32)e);
-                const u32 xs = __builtin_amdgcn_ubfe(my, 2, 7), row = my >> 9;
-                const u32 s = lds_r8(cbase + scD + row * (u32)Pb + xs);
-                if (e < L.slotCap)
-                    out[e] = (u32)((int)ax.outx + (int)xs) | ((u32)((int)ax.outy + (int)row) << 12) | (s << 24);
-                else atomicExch(err, 1);
-            }
-        }
-        if (lane == 0) candCnt[(size_t)frame * g.totalCells + ax.cnt] = (u32)n3;
+        F4Ctx cx; cx.imgA = imgA; cx.scD = scD; cx.qA = qA; cx.cbase = imgA + ax.base; cx.Pb = Pb; cx.qcap = qcap; cx.lane = lane;
+#ifdef F4_ABL_NOQUICK
+        const int n1 = 0;
+#else
+        const int n1 = ax.nit > 0 ? f4_quick<PITCH>(cx, ax, items, g.iniTh) : 0;
+#endif
+        f4_finish<PITCH>(g, cx, ax, items, n1, L.slotCap, frame, st.cell0 + c, candCnt, candEnt, err, ovf, ovfList);
     }
 }
 
@@ -1033,7 +1098,7 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const CellInfo* __rest
     for (int i = tid; i < cap; i += 256) { S.cnt[i] = 0; S.split[i] = 0; }
     __syncthreads();
     for (int c = wv; c < L.nCells; c += 4) {
-        const int n = (int)cnts[c];
+        const int n = (int)min(cnts[c], (u32)L.slotCap);
         const int sb = cells[L.cellBase + c].slot;
         for (int k = lane; k < n; k += 64) {
             const u32 e = ents[sb + k];
@@ -1068,7 +1133,7 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const CellInfo* __rest
         for (int i = tid; i < cap * 4; i += 256) S.qc[i] = 0;
         __syncthreads();
         for (int c = wv; c < L.nCells; c += 4) {
-            const int n = (int)cnts[c];
+            const int n = (int)min(cnts[c], (u32)L.slotCap);
             const int sb = cells[L.cellBase + c].slot;
             for (int k = lane; k < n; k += 64) {
                 const int nd = kn[sb + k];
@@ -1172,7 +1237,7 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const CellInfo* __rest
         __syncthreads();
         // (3) move the keypoints of split nodes to their children
         for (int c = wv; c < L.nCells; c += 4) {
-            const int n = (int)cnts[c];
+            const int n = (int)min(cnts[c], (u32)L.slotCap);
             const int sb = cells[L.cellBase + c].slot;
             for (int k = lane; k < n; k += 64) {
                 const int nd = kn[sb + k];
@@ -1199,7 +1264,7 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const CellInfo* __rest
     for (int i = tid; i < cap; i += 256) S.best[i] = 0;
     __syncthreads();
     for (int c = wv; c < L.nCells; c += 4) {
-        const int n = (int)cnts[c];
+        const int n = (int)min(cnts[c], (u32)L.slotCap);
         const int sb = cells[L.cellBase + c].slot;
         for (int k = lane; k < n; k += 64) {
             const u32 e = ents[sb + k];
@@ -1341,7 +1406,7 @@ __global__ __launch_bounds__(NT) void k_quadtree2(Geom g, const u32* __restrict_
 
     // ---- gather the per-cell slot arrays into one dense list (cells are stored in reference order)
     const int nCells = L.nCells;
-    for (int c = tid; c < nCells; c += NT) cellOff[c] = cnts[c];
+    for (int c = tid; c < nCells; c += NT) cellOff[c] = min(cnts[c], (u32)L.slotCap);   // (never beyond a cell's slots, whatever the count word holds)
     for (int i = tid; i < cap; i += NT) s1[i] = 0;
     for (int i = tid; i < (maxIni << (2 * fuseD)); i += NT) HD[i] = 0;
     __syncthreads();
