@@ -129,7 +129,7 @@ class StubWorkload:
         pass
 
     def step(self):
-        time.sleep(0.002)
+        time.sleep(0.02 if os.environ.get("ORB_BENCH_STUB_SLOW_RANK") == str(self.rank) else 0.002)   # (a straggler, for the per-rank times)
 
     def flush(self):
         pass
@@ -381,10 +381,12 @@ def timed_loop(wl, steps, barrier):
         if hasattr(wl, "mark"):
             wl.mark(1)
         wl.sync()
+        t_own = time.perf_counter() - t0                    # this rank's own K steps, before it waits for the others
         barrier()
         dt = time.perf_counter() - t0
     finally:
         gc.enable()
+    timed_loop.last_own = t_own
     return dt, t_enq
 
 
@@ -542,6 +544,41 @@ def c3_verify(wl, blk):
     return bool(ok), int(kept_h.sum()), int(nm_h.sum())
 
 
+def pin_to_gpu_numa_node(local_rank):
+    """Host threads of a rank (enqueue loop, copy thread, RCCL proxy) stay on the CPUs of the NUMA node its GPU hangs off:
+    /sys/class/drm/card*/device of the AMD GPUs (vendor 0x1002, in PCI bus order) -> numa_node -> that node's cpulist.  Best effort:
+    returns what was done, None where the topology cannot be read (containers without /sys, single-node hosts report -1)."""
+    if os.environ.get("ORB_BENCH_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        import glob
+        cards = []
+        for d in glob.glob("/sys/class/drm/card[0-9]*/device"):
+            try:
+                if open(os.path.join(d, "vendor")).read().strip() == "0x1002":
+                    cards.append((os.path.basename(os.path.realpath(d)), d))        # PCI address orders them as the runtime does
+            except OSError:
+                continue
+        cards.sort()
+        if not cards:
+            return None
+        d = cards[local_rank % len(cards)][1]
+        node = int(open(os.path.join(d, "numa_node")).read().strip())
+        if node < 0:
+            return {"numa_node": node, "pinned": False}
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)                          # never widen what the launcher / cgroup allows
+        if not cpus:
+            return {"numa_node": node, "pinned": False}
+        os.sched_setaffinity(0, cpus)
+        return {"numa_node": node, "pinned": True, "cpus": len(cpus)}
+    except Exception:
+        return None
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -553,6 +590,7 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     stub = os.environ.get("ORB_BENCH_STUB") == "1"
 
+    pin = pin_to_gpu_numa_node(local_rank) if not stub else None     # before torch / HIP start their threads: they inherit the mask
     import numpy as np
     import torch                       # plumbing: device sync + torch.distributed (RCCL); imported BEFORE the
     import torch.distributed as dist   # HIP library so both share one libamdhip64 runtime
@@ -584,6 +622,7 @@ def main():
         wl.step()
     wl.sync()
     dt, t_enq = timed_loop(wl, args.steps, barrier)          # the metric: kernels + results to the host
+    dt_own = timed_loop.last_own
     gpu_wall = wl.mark_ms() if not stub else None
     extra = {}
     if not stub:
@@ -591,6 +630,7 @@ def main():
         # replay of every graph slot, i.e. the last steps of the timed region)
         tm, nsamp = wl.ex.mean_timings()
         span_ms, total_ms = tm["pyramid_fast_span"], tm["total"]
+        pf_only_ms = tm["fast"]                            # (stage timing off: first launch -> end of the last FAST launch)
         match_ms = wl.mt.timing_ms()
         # the same loop with the results left in HBM (round-1's figure)
         wl.download = False
@@ -599,7 +639,7 @@ def main():
         wl.sync()
         dt_res, t_enq_res = timed_loop(wl, args.steps, barrier)
         wl.download = True
-        extra = dict(span_ms=span_ms, total_ms=total_ms, match_ms=match_ms, nsamp=nsamp, dt_res=dt_res, t_enq_res=t_enq_res)
+        extra = dict(span_ms=span_ms, pf_only_ms=pf_only_ms, total_ms=total_ms, match_ms=match_ms, nsamp=nsamp, dt_res=dt_res, t_enq_res=t_enq_res)
 
     n_host = wl.counts()
     dmod = importlib.import_module("orb-slam3_amd.dist")
@@ -609,6 +649,15 @@ def main():
     # RCCL: the path's only exchange -- per-frame keypoint counts of every rank
     gathered = dmod.gather_counts(n_host, device=cdev)
     total_kp = int(torch.stack([g.sum() for g in gathered]).sum().item())
+    # every rank's own time for its K steps, measured before the closing barrier (a straggler shows here; `value` uses the
+    # barrier-to-barrier maximum)
+    mine = torch.tensor([dt_own], dtype=torch.float64, device=cdev)
+    if world > 1:
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in allr]
+    else:
+        per_rank_ms = [dt_own / args.steps * 1e3]
     dt, dt_res = float(tmax[0].item()), float(tmax[1].item())
 
     if rank == 0:
@@ -616,7 +665,7 @@ def main():
         out = {
             "metric": None, "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
+            "dtype": "u8", "data": "synthetic", "per_rank_ms_per_step": per_rank_ms, "cpu_affinity_rank0": pin,
         }
         if stub:
             out["metric"] = "stub (no GPU work): launcher / rendezvous / gather rehearsal"
@@ -659,16 +708,36 @@ def report(wl, args, world, dt, dt_res, t_enq, gpu_wall, extra, total_kp, frames
     alg_pf = alg
     if blur_in:
         alg = alg + 2 * (alg - fused)
-    pf_ms = extra["span_ms"]
+    pf_ms = extra["span_ms"]                                    # the pass: first launch -> later of (last FAST launch, in-pass blur)
+    pfo_ms = extra["pf_only_ms"] or pf_ms                      # first launch -> end of the last FAST launch (pyramid+FAST proper)
     achieved = alg * B / (pf_ms * 1e-3) / 1e9
-    traffic, traffic_src = None, None                  # HBM bytes per launch group from the committed rocprofv3 --pmc passes
-    for name in ("r02_traffic_%s.json" % wl.cfg, "r02_traffic.json", "r01_traffic.json"):
+    achieved_pf = alg_pf * B / (pfo_ms * 1e-3) / 1e9
+    traffic, traffic_pf, traffic_src = None, None, None        # HBM bytes per launch group from the committed rocprofv3 --pmc passes
+    for name in ("r03_traffic_%s.json" % wl.cfg, "r03_traffic.json", "r02_traffic_%s.json" % wl.cfg, "r02_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
             c = tj["config"]
             if (c["width"], c["height"], c["nfeatures"]) == (W, H, nF):
+                traffic_pf = tj["pyramid_fast_bytes_per_frame"] * B
                 traffic = (tj["pyramid_fast_bytes_per_frame"] + (tj["blur_bytes_per_frame"] if blur_in else 0)) * B
-                traffic_src = "profiles/" + name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per frame x frames per launch)"
+                traffic_src = "profiles/" + name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at batch %d, per frame x frames per launch)" % c["batch"]
+                break
+        except Exception:
+            continue
+    # the other roofline of this pass: integer VALU issue.  Wave-instructions per frame from the committed SQ_INSTS_VALU pass, issue
+    # rate from the committed micro-benchmark; the span is the live one of this run.
+    valu = None
+    for name in ("r03_valu_%s.json" % wl.cfg, "r03_valu.json"):
+        try:
+            vj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            c = vj["config"]
+            if (c["width"], c["height"], c["nfeatures"]) == (W, H, nF):
+                pp = vj["pass_per_frame"]
+                wi = (pp["resize"] + pp["fast"] + (pp["blur"] if blur_in else 0.0)) * B
+                valu = {"wave_instr_per_launch": wi, "achieved": wi / (pf_ms * 1e-3), "peak": vj["peak_wave_instr_per_s"], "unit": "wave-instr/s",
+                        "frac": wi / (pf_ms * 1e-3) / vj["peak_wave_instr_per_s"],
+                        "kernels": "k_resize2 x7 + k_fast4 x3 + k_fast_fix" + (" + k_blur3" if blur_in else "") + " over the pass span (launch_ms)",
+                        "source": "profiles/%s (SQ_INSTS_VALU, rocprofv3 --pmc at batch %d, per frame x frames per launch); peak: %s" % (name, c["batch"], vj["peak_source"])}
                 break
         except Exception:
             continue
@@ -713,20 +782,22 @@ def report(wl, args, world, dt, dt_res, t_enq, gpu_wall, extra, total_kp, frames
         "host_loop_ms_per_step": t_enq / args.steps * 1e3,
         "gpu_wall_ms_per_step": gpu_wall / args.steps,
         "gpu_total_ms_per_step": extra["total_ms"] + match_ms,
-        "roofline": {"bound": "hbm", "kernel": ("pyramid+FAST+blur pass (k_resize2 x7 then k_blur3 on stream 2 + k_fast3 x3 and k_fast_fix on stream 1; wall span by HIP events)"
-                                if blur_in else "pyramid+FAST pass (k_resize2 x7 on stream 2 + k_fast3 x3 and k_fast_fix on stream 1; wall span by HIP events)"),
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": alg * B, "frames_per_launch": B, "algorithmic_bytes_per_frame": alg,
-                     "fused_lower_bound_per_frame": fused, "launch_ms": pf_ms, "launch_samples": extra["nsamp"],
+        # Headline figure = pyramid+FAST proper (SURVEY 8(d)'s object): its algorithmic bytes over the live span from the first launch to
+        # the end of the last FAST launch.  What BINDS the pass is integer VALU issue, not HBM: `valu` holds that roofline (whole pass,
+        # blur included, because the blur shares the window and the pipes), `with_blur` the HBM figure of the whole pass.
+        "roofline": {"bound": ("valu" if valu and valu["frac"] > achieved / HBM_PEAK_GBS else "hbm"),
+                     "kernel": "pyramid+FAST pass (k_resize2 x7 on stream 2 + k_fast4 x3 and k_fast_fix on stream 1; wall span by HIP events / on-stream stamps, "
+                               "first launch -> end of the last FAST launch" + ("; k_blur3 runs beside it on stream 2)" if blur_in else ")"),
+                     "achieved": achieved_pf, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_pf / HBM_PEAK_GBS,
+                     "traffic": traffic_pf, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": alg_pf * B, "frames_per_launch": B, "algorithmic_bytes_per_frame": alg_pf,
+                     "fused_lower_bound_per_frame": fused, "launch_ms": pfo_ms, "launch_samples": extra["nsamp"],
                      "measured_copy_peak_GBps": copy_gbs,
-                     # for continuity with the pyramid+FAST-only figure: its own bytes over the span to the end of the last FAST
-                     # launch (stage events of the untimed staged pass; FAST is stretched by the blur running beside it)
-                     "pyramid_fast_only": ({"algorithmic_bytes_per_frame": alg_pf, "span_ms": stage["fast"],
-                                            "achieved": alg_pf * B / (stage["fast"] * 1e-3) / 1e9,
-                                            "frac": alg_pf * B / (stage["fast"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                                           if blur_in and stage.get("fast", 0) > 0 else None),
-                     "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None},
+                     "frac_of_measured_copy": (achieved_pf / copy_gbs) if copy_gbs else None,
+                     "valu": valu,
+                     "with_blur": ({"kernel": "the same pass with k_blur3 (scheduled inside it): span to the later of FAST and blur",
+                                    "algorithmic_bytes_per_frame": alg, "launch_ms": pf_ms, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                                    "traffic": traffic} if blur_in else None)},
         "stage_ms_per_step": stage,
     }
     # host copy == device results (outside the timed region): one more step, then compare its pinned copy with per-frame fetches

@@ -107,7 +107,8 @@ int orbx_last_timings(orbx_t*, float* ms8);
  * blur's read + write of every level (2 * sum of level pixels).  0 with ORBX_BLUR_V2 / ORBX_BLUR_LATE. */
 int orbx_blur_in_pass(const orbx_t*);
 /* stage-boundary events are optional: with `on` = 0 only the dependency events are recorded (a few microseconds less per
- * batch); orbx_last_timings / orbx_mean_timings then fill ms8[6] (total) and ms8[7] (pyramid+FAST span) and zero the rest.
+ * batch); orbx_last_timings / orbx_mean_timings then fill ms8[6] (total), ms8[7] (the pass: to the later of FAST and an in-pass blur)
+ * and ms8[1] (first launch -> end of the last FAST launch, i.e. pyramid+FAST without the blur's tail) and zero the rest.
  * Default on.  Restarts the timing ring. */
 int orbx_set_stage_timing(orbx_t*, int on);
 /* mean of the same 8 figures over the most recent (<= 32) enqueued batches; *nsamples = how many were averaged.

@@ -1542,6 +1542,7 @@ static int timings_of(orbx* o, hipEvent_t* ev, float* ms7) {
         for (int i = 0; i < 6; ++i) ms7[i] = 0.f;
         HIPCHK(hipEventElapsedTime(&ms7[6], ev[0], ev[6]));
         HIPCHK(hipEventElapsedTime(&ms7[7], ev[0], ev[2]));
+        ms7[1] = ms7[7];                                     // start -> end of the last FAST launch: the pyramid+FAST span proper
         if (o->blurEarly && !o->serial) {
             float b = 0;
             HIPCHK(hipEventElapsedTime(&b, ev[0], ev[9]));
@@ -1593,6 +1594,7 @@ int orbx_mean_timings(orbx_t* o, float* ms8, int* nsamples) {
             const unsigned long long* t = st + 4 * k;
             unsigned long long passEnd = t[1];
             if (o->blurEarly && !o->serial && t[2] > passEnd) passEnd = t[2];
+            acc[1] += (double)(t[1] - t[0]) * msPerTick;     // start -> end of the last FAST launch (no per-stage events in a replay)
             acc[6] += (double)(t[3] - t[0]) * msPerTick;
             acc[7] += (double)(passEnd - t[0]) * msPerTick;
             ++n;

@@ -84,3 +84,24 @@ def test_bench_launcher_reports_a_failed_rank():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
+
+
+def test_bench_launcher_eight_ranks_and_a_straggler():
+    """The shape of the driver's 8-GPU run, rehearsed on CPU: 8 rank processes, one JSON line with 8 per-rank step times in which
+    the slow rank stands out and sets the whole-job value (max over ranks)."""
+    import json
+    import subprocess
+    env = dict(os.environ, ORB_BENCH_STUB="1", ORB_BENCH_BACKEND="gloo", ORB_BENCH_STUB_SLOW_RANK="5")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "1", "--batch", "3"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and len(d["per_rank_ms_per_step"]) == 8
+    pr = d["per_rank_ms_per_step"]
+    assert max(range(8), key=lambda r: pr[r]) == 5 and pr[5] > 15.0 and max(pr[r] for r in range(8) if r != 5) < 10.0
+    assert d["ms_per_step"] >= pr[5] - 1e-6                        # the whole job runs at the straggler's pace
+    assert d["config"]["keypoints_last_batch"] == sum(3 * (1000 + r) for r in range(8))
