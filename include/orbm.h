@@ -242,7 +242,23 @@ int orbm_search_for_triangulation_gated(orbm_t*, int n1, const orbm_kp_t* kps1, 
  * orbm_track_window_batch_async: for pair p the keypoints of frame q_first+p search frame t_first+p inside the mono
  * SearchByProjection window (centre (x+dx, y+dy), radius th*scale[octave], levels octave-1..octave+1,
  * ORBmatcher.cc:2543-2549): first-minimum best index/distance and runner-up distance per keypoint, [npairs][cap].
- * This is the claim-free, data-parallel part; sequential claim replay (M4) needs the host entry point above. */
+ * This is the claim-free, data-parallel part; the final matches of the batch: orbm_search_by_projection_batch_async. */
+/* orbm_search_by_projection_batch_async: M4 SearchByProjection(CurrentFrame, LastFrame, th, bMono = true) END TO END on the device
+ * for `npairs` frame pairs of one result block (ORBmatcher.cc:2469-2711, the monocular branch: no mvuRight gate, window levels
+ * octave-1..octave+1).  Pair p: the keypoints of frame q_first+p play LastFrame's MapPoints in index order -- every one valid,
+ * projected to (x+dx, y+dy), carrying its own descriptor, octave and angle -- and search frame t_first+p through its grid.
+ * t_blocked [frames][cap] (device, indexed by FRAME id; NULL = none): slots of the searched frame that already hold a MapPoint
+ * with observations (:2565-2567).  q_obs [frames][cap] (NULL = all 1): pMP->Observations() > 0 of the query's MapPoint, i.e.
+ * whether its assignment blocks later queries.  The claim sequence, `bestDist <= TH_HIGH`, the rotation histogram and the
+ * ComputeThreeMaxima cull (:2595-2605, 2690-2708) run in query order on the device.  Outputs (device): match [npairs][cap] =
+ * query index assigned to that slot of the searched frame, ORBM_NO_MATCH or ORBM_MATCH_PRUNED -- the same row
+ * orbm_search_by_projection_frame returns for the pair --, nmatches [npairs] = its return value.  Enqueue-only (capturable). */
+int orbm_search_by_projection_batch_async(orbm_t*, const orbm_kp_t* kps, const uint8_t* desc, const int32_t* counts, int cap,
+                                          const int32_t* grid_start, const int32_t* grid_idx,
+                                          float min_x, float min_y, float inv_w, float inv_h,
+                                          int q_first, int t_first, int npairs, float th, const float* scale_factors_host, int nlevels,
+                                          float dx, float dy, const uint8_t* t_blocked, const uint8_t* q_obs, int check_orientation,
+                                          int32_t* match, int32_t* nmatches);
 int orbm_grid_build_batch_async(orbm_t*, const orbm_kp_t* kps, const int32_t* counts, int nframes, int cap,
                                 float min_x, float min_y, float inv_w, float inv_h, int32_t* grid_start, int32_t* grid_idx);
 int orbm_track_window_batch_async(orbm_t*, const orbm_kp_t* kps, const uint8_t* desc, const int32_t* counts, int cap,

@@ -817,6 +817,10 @@ def _install_search():
     L.orbm_track_window_batch_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float,
                                                 C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orbm_search_by_projection_batch_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float,
+                                                        C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
+                                                        C.c_void_p, C.c_void_p]
     L.orbm_vocab_load_text.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_char_p]
     L.orbm_vocab_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orbm_vocab_destroy.argtypes = [C.c_void_p]
@@ -891,7 +895,7 @@ EXPORTS += ["orbm_grid_build", "orbm_window_candidates", "orbm_search_by_project
             "orbm_search_for_initialization", "orbm_search_for_triangulation", "orbm_search_by_bow", "orbm_stereo_matches",
             "orbm_search_by_projection_kf", "orbm_search_by_bow_kf", "orbm_search_for_triangulation_legacy", "orbm_search_for_triangulation_gated",
             "orbm_search_by_projection_sim3", "orbm_fuse", "orbm_search_by_sim3",
-            "orbm_grid_build_batch_async", "orbm_track_window_batch_async", "orbm_search_by_projection_frame_fisheye",
+            "orbm_grid_build_batch_async", "orbm_track_window_batch_async", "orbm_search_by_projection_batch_async", "orbm_search_by_projection_frame_fisheye",
             "orbm_search_by_projection_points_fisheye", "orbm_search_by_bow_fisheye",
             "orbm_vocab_load_text", "orbm_vocab_create", "orbm_vocab_destroy", "orbm_vocab_info", "orbm_bow_transform", "orbm_bow_vectors"]
 _orig_lib = lib

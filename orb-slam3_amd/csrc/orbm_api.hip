@@ -1116,6 +1116,38 @@ int orbm_track_window_batch_async(orbm_t* m, const orbm_kp_t* kps, const uint8_t
     return ORBM_OK;
 }
 
+int orbm_search_by_projection_batch_async(orbm_t* m, const orbm_kp_t* kps, const uint8_t* desc, const int32_t* counts, int cap,
+                                          const int32_t* grid_start, const int32_t* grid_idx,
+                                          float min_x, float min_y, float inv_w, float inv_h,
+                                          int q_first, int t_first, int npairs, float th, const float* sf, int nlevels,
+                                          float dx, float dy, const uint8_t* t_blocked, const uint8_t* q_obs, int check_orientation,
+                                          int32_t* match, int32_t* nmatches) {
+    if (!m || !kps || !desc || !counts || !grid_start || !grid_idx || !match || !nmatches || npairs < 1 || cap < 1 || cap > 65535 ||
+        nlevels < 1 || nlevels > 12 || !sf || q_first < 0 || t_first < 0) return ORBM_E_INVALID;
+    MHIPCHK(hipSetDevice(m->device));
+    ScaleTab st;
+    for (int i = 0; i < 12; ++i) st.sf[i] = i < nlevels ? sf[i] : sf[nlevels - 1];
+    // scratch of the handle: per query the window population and its TK_K best candidates, per pair the (slot, bin) list of the assignments
+    const size_t rows = (size_t)npairs * cap;
+    const size_t bCnt = (rows * sizeof(int) + 255) & ~(size_t)255, bKeys = (rows * TK_K * sizeof(unsigned) + 255) & ~(size_t)255,
+                 bAcc = (rows * sizeof(unsigned) + 255) & ~(size_t)255;
+    uint8_t* scr = batch_scratch(m, bCnt + bKeys + bAcc);
+    if (!scr) { set_merr("SearchByProjection batch scratch of %zu B unavailable (inside a capture, run the call once eagerly first)", bCnt + bKeys + bAcc); return ORBM_E_HIP; }
+    int* topCnt = (int*)scr; unsigned* topKeys = (unsigned*)(scr + bCnt); unsigned* acc = (unsigned*)(scr + bCnt + bKeys);
+    const float factor = ORBM_HISTO_LENGTH / 360.0f;                        // ORBmatcher.cc:2478
+    const size_t lds = (size_t)(((cap + 31) >> 5) + 32) * sizeof(unsigned);
+    MHIPCHK(rec_time(m, m->e0));
+    hipLaunchKernelGGL(k_track_topk, dim3((cap + 3) / 4, npairs), dim3(256), 0, m->stream, (const KpIn*)kps, desc, counts, cap,
+                       grid_start, grid_idx, min_x, min_y, inv_w, inv_h, q_first, t_first, th, st, dx, dy, factor, topCnt, topKeys);
+    hipLaunchKernelGGL(k_track_claim, dim3(npairs), dim3(64), lds, m->stream, (const KpIn*)kps, desc, counts, cap,
+                       grid_start, grid_idx, min_x, min_y, inv_w, inv_h, q_first, t_first, th, st, dx, dy, factor, topCnt, topKeys,
+                       t_blocked, q_obs, check_orientation, acc, match, nmatches);
+    MHIPCHK(rec_time(m, m->e1));
+    MHIPCHK(hipGetLastError());
+    m->timed = true;
+    return ORBM_OK;
+}
+
 // ---- DBoW2 vocabulary ----
 struct orbm_vocab {
     int k = 0, L = 0, nnodes = 0, nwords = 0, device = 0;

@@ -1084,6 +1084,252 @@ __global__ __launch_bounds__(256) void k_track_window(const KpIn* __restrict__ k
 }
 
 // ------------------------------------------------------------------------------------------------
+// Batched SearchByProjection(Frame, Frame), final matches on the device (ORBmatcher.cc:2469-2711, mono branch).
+// k_track_topk: wave per query keypoint (same window as k_track_window).  What the sequential claim replay can ever look at:
+//   the window's candidate count and its TK_K best candidates in (distance, visiting order) rank -- the order in which the
+//   reference's `dist < bestDist` scan would prefer them -- each as ONE word: dist << 21 | rotation bin << 16 | keypoint index
+//   (bin = round((angle_q - angle_t [+360]) * 30/360), 30 -> 0, ORBmatcher.cc:2596-2603; the replay needs no second gather).
+// k_track_claim: ONE wave per frame pair replays the claims in query order (:2555-2593): a query takes its first candidate that is
+//   not blocked (a MapPoint with observations already sits there: cur_blocked, or an earlier query with observations claimed it,
+//   :2565-2567), bestDist <= TH_HIGH assigns the slot (:2589-2592), the rotation histogram keeps (slot, bin) of every assignment
+//   and the three-maxima cull clears the others (:2690-2708).  Eight queries' lists (8 x 8 keys) are fetched per round trip and the
+//   next eight are requested before the current ones are resolved; the blocked set is a bit array in LDS, claims inside a group
+//   travel by register compare.  A query whose TK_K listed candidates are all blocked although its window holds more is rescanned
+//   in place, blocked set applied (rare; the single-frame host replay falls back to full lists in the same case).
+// ------------------------------------------------------------------------------------------------
+#define TK_K 8
+#define TK_NOBIN 31
+__global__ __launch_bounds__(256) void k_track_topk(const KpIn* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                    const int* __restrict__ counts, int cap, const int* __restrict__ grid_start,
+                                                    const int* __restrict__ grid_idx, float min_x, float min_y, float inv_w, float inv_h,
+                                                    int q_first, int t_first, float th, ScaleTab st, float dx, float dy, float factor,
+                                                    int* __restrict__ out_cnt, unsigned int* __restrict__ out_keys) {
+    const int lane = threadIdx.x & 63;
+    const int pair = blockIdx.y;
+    const int qf = q_first + pair, tf = t_first + pair;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= min(counts[qf], cap)) return;
+    const KpIn kq = kps[(size_t)qf * cap + q];
+    const KpIn* kt = kps + (size_t)tf * cap;
+    const uint8_t* dt = desc + (size_t)tf * cap * 32;
+    const int* gs = grid_start + (size_t)tf * (64 * 48 + 1);
+    const int* gi = grid_idx + (size_t)tf * cap;
+    const float x = kq.x + dx, y = kq.y + dy, r = th * st.sf[kq.octave];
+    const int minLevel = kq.octave - 1, maxLevel = kq.octave + 1;
+    const u64 INV = ~0ull;
+    u64 top[TK_K];
+#pragma unroll
+    for (int i = 0; i < TK_K; ++i) top[i] = INV;
+    int cnt = 0;
+    const int nMinCellX = max(0, (int)floorf((x - min_x - r) * inv_w));
+    const int nMaxCellX = min(63, (int)ceilf((x - min_x + r) * inv_w));
+    const int nMinCellY = max(0, (int)floorf((y - min_y - r) * inv_h));
+    const int nMaxCellY = min(47, (int)ceilf((y - min_y + r) * inv_h));
+    if (nMinCellX < 64 && nMaxCellX >= 0 && nMinCellY < 48 && nMaxCellY >= 0) {
+        const uint4* qp = (const uint4*)(desc + ((size_t)qf * cap + q) * 32);
+        const uint4 qlo = qp[0], qhi = qp[1];
+        const u64 a[4] = {(u64)qlo.x | ((u64)qlo.y << 32), (u64)qlo.z | ((u64)qlo.w << 32),
+                          (u64)qhi.x | ((u64)qhi.y << 32), (u64)qhi.z | ((u64)qhi.w << 32)};
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int ix = nMinCellX; ix <= nMaxCellX; ++ix) {
+            const int j0 = gs[ix * 48 + nMinCellY], j1 = gs[ix * 48 + nMaxCellY + 1];
+            for (int jb = j0; jb < j1; jb += 64) {
+                const int j = jb + lane;
+                bool ok = false;
+                int k = 0;
+                float ang = 0.f;
+                if (j < j1) {
+                    k = gi[j];
+                    const KpIn kp = kt[k];
+                    ok = !(kp.octave < minLevel) && !(kp.octave > maxLevel);   // bCheckLevels is true here (maxLevel >= 0)
+                    if (!(fabsf(kp.x - x) < r && fabsf(kp.y - y) < r)) ok = false;
+                    ang = kp.angle;
+                }
+                const unsigned long long bal = __ballot(ok);
+                u64 key = INV;
+                if (ok) {
+                    const int pos = cnt + __popcll(bal & lt);
+                    const uint4* tp = (const uint4*)(dt + (size_t)k * 32);
+                    const uint4 lo = tp[0], hi = tp[1];
+                    const int d = ham256(a, (u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
+                                         (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32));
+                    float rot = kq.angle - ang;
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == 30) bin = 0;
+                    if (bin < 0 || bin >= 30) bin = TK_NOBIN;
+                    key = ((u64)d << 44) | ((u64)pos << 24) | ((u64)bin << 16) | (u64)k;
+                }
+                cnt += __popcll(bal);
+                if (bal == 0) continue;
+                for (int rnd = 0; rnd < TK_K; ++rnd) {           // merge this chunk into the running top-K (keys are unique: position)
+                    const u64 m = wave_min_u64(key);
+                    if (m >= top[TK_K - 1]) break;
+                    if (key == m) key = INV;
+                    u64 c = m;
+#pragma unroll
+                    for (int i = 0; i < TK_K; ++i) { const u64 t = top[i]; const bool sw = c < t; top[i] = sw ? c : t; c = sw ? t : c; }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        const size_t o = (size_t)pair * cap + q;
+        out_cnt[o] = cnt;
+#pragma unroll
+        for (int i = 0; i < TK_K; ++i)
+            out_keys[o * TK_K + i] = top[i] == INV ? 0xFFFFFFFFu : ((unsigned)(top[i] >> 44) << 21) | (unsigned)(top[i] & 0x1FFFFFu);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_track_claim(const KpIn* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                    const int* __restrict__ counts, int cap, const int* __restrict__ grid_start,
+                                                    const int* __restrict__ grid_idx, float min_x, float min_y, float inv_w, float inv_h,
+                                                    int q_first, int t_first, float th, ScaleTab st, float dx, float dy, float factor,
+                                                    const int* __restrict__ topCnt, const unsigned int* __restrict__ topKeys,
+                                                    const uint8_t* __restrict__ t_blocked, const uint8_t* __restrict__ q_obs, int check_ori,
+                                                    unsigned int* __restrict__ accepted, int* __restrict__ match, int* __restrict__ nmatches) {
+    extern __shared__ unsigned int tk_lds[];                                // blocked bit array [ceil(cap / 32)] then hist[32]
+    const int lane = threadIdx.x, pair = blockIdx.x;
+    const int qf = q_first + pair, tf = t_first + pair;
+    const int nq = min(counts[qf], cap), nt = min(counts[tf], cap);
+    const int nwords = (cap + 31) >> 5;
+    unsigned int* blk = tk_lds;
+    unsigned int* hist = tk_lds + nwords;
+    int* mrow = match + (size_t)pair * cap;
+    unsigned int* acc = accepted + (size_t)pair * cap;
+    for (int w = lane; w < nwords; w += 64) {
+        unsigned int bits = 0;
+        if (t_blocked) {
+            const uint8_t* tb = t_blocked + (size_t)tf * cap + (size_t)w * 32;
+            for (int b = 0; b < 32; ++b) if (w * 32 + b < nt && tb[b]) bits |= 1u << b;
+        }
+        blk[w] = bits;
+    }
+    if (lane < 32) hist[lane] = 0;
+    for (int k = lane; k < cap; k += 64) mrow[k] = -1;                        // ORBM_NO_MATCH
+    __syncthreads();
+    const size_t rowBase = (size_t)pair * cap;
+    const int sub = lane >> 3;                                              // the lane's query inside a group of eight
+    int nm = 0, nacc = 0;
+    unsigned int key = 0xFFFFFFFFu;
+    int cnt = 0;
+    {   // first group
+        const int qi = sub;
+        if (qi < nq) { key = topKeys[(rowBase + qi) * TK_K + (lane & 7)]; cnt = topCnt[rowBase + qi]; }
+    }
+    for (int g0 = 0; g0 < nq; g0 += 8) {
+        // request the next group's lists before resolving this one
+        unsigned int nkey = 0xFFFFFFFFu;
+        int ncnt = 0;
+        {
+            const int qi = g0 + 8 + sub;
+            if (qi < nq) { nkey = topKeys[(rowBase + qi) * TK_K + (lane & 7)]; ncnt = topCnt[rowBase + qi]; }
+        }
+        const bool valid = key != 0xFFFFFFFFu;
+        const unsigned int myk = key & 0xFFFFu;
+        bool blocked = valid && ((blk[myk >> 5] >> (myk & 31)) & 1u);       // as of the start of the group; claims inside it: below
+        const int gend = min(8, nq - g0);
+        for (int s = 0; s < gend; ++s) {
+            const int qi = g0 + s;
+            const unsigned long long sel = 0xFFull << (8 * s);
+            const unsigned long long bal = __ballot(valid && !blocked) & sel;
+            unsigned int best = 0xFFFFFFFFu;
+            if (bal) best = (unsigned int)__shfl((int)key, __ffsll((long long)bal) - 1);
+            else {
+                const int c = __shfl(cnt, 8 * s);
+                if (c > TK_K) {
+                    // every listed candidate is blocked but the window holds more: scan it again with the blocked set applied
+                    const KpIn kq = kps[(size_t)qf * cap + qi];
+                    const KpIn* kt = kps + (size_t)tf * cap;
+                    const uint8_t* dt = desc + (size_t)tf * cap * 32;
+                    const int* gs = grid_start + (size_t)tf * (64 * 48 + 1);
+                    const int* gi = grid_idx + (size_t)tf * cap;
+                    const float x = kq.x + dx, y = kq.y + dy, r = th * st.sf[kq.octave];
+                    const int minLevel = kq.octave - 1, maxLevel = kq.octave + 1;
+                    const int nMinCellX = max(0, (int)floorf((x - min_x - r) * inv_w));
+                    const int nMaxCellX = min(63, (int)ceilf((x - min_x + r) * inv_w));
+                    const int nMinCellY = max(0, (int)floorf((y - min_y - r) * inv_h));
+                    const int nMaxCellY = min(47, (int)ceilf((y - min_y + r) * inv_h));
+                    const uint4* qp = (const uint4*)(desc + ((size_t)qf * cap + qi) * 32);
+                    const uint4 qlo = qp[0], qhi = qp[1];
+                    const u64 a[4] = {(u64)qlo.x | ((u64)qlo.y << 32), (u64)qlo.z | ((u64)qlo.w << 32),
+                                      (u64)qhi.x | ((u64)qhi.y << 32), (u64)qhi.z | ((u64)qhi.w << 32)};
+                    u64 bk = ~0ull;
+                    int ord0 = 0;
+                    for (int ix = nMinCellX; ix <= nMaxCellX; ++ix) {
+                        const int j0 = gs[ix * 48 + nMinCellY], j1 = gs[ix * 48 + nMaxCellY + 1];
+                        for (int jb = j0; jb < j1; jb += 64) {
+                            const int j = jb + lane;
+                            if (j < j1) {
+                                const int k = gi[j];
+                                const KpIn kp = kt[k];
+                                bool ok = !(kp.octave < minLevel) && !(kp.octave > maxLevel);
+                                if (!(fabsf(kp.x - x) < r && fabsf(kp.y - y) < r)) ok = false;
+                                if (ok && !((blk[k >> 5] >> (k & 31)) & 1u)) {
+                                    const uint4* tp = (const uint4*)(dt + (size_t)k * 32);
+                                    const uint4 lo = tp[0], hi = tp[1];
+                                    const int d = ham256(a, (u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
+                                                         (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32));
+                                    float rot = kq.angle - kp.angle;
+                                    if (rot < 0.0f) rot += 360.0f;
+                                    int bin = (int)roundf(rot * factor);
+                                    if (bin == 30) bin = 0;
+                                    if (bin < 0 || bin >= 30) bin = TK_NOBIN;
+                                    // (order among grid entries, not among window members: monotone in it, which is all the first-minimum rule needs)
+                                    const u64 kk = ((u64)d << 44) | ((u64)(ord0 + (j - j0)) << 24) | ((u64)bin << 16) | (u64)k;
+                                    bk = kk < bk ? kk : bk;
+                                }
+                            }
+                        }
+                        ord0 += j1 - j0;
+                    }
+                    bk = wave_min_u64(bk);
+                    if (bk != ~0ull) best = ((unsigned)(bk >> 44) << 21) | (unsigned)(bk & 0x1FFFFFu);
+                }
+            }
+            if (best == 0xFFFFFFFFu) continue;
+            const int d = (int)(best >> 21);
+            if (d > 100) continue;                                          // TH_HIGH (:2589)
+            const unsigned int k = best & 0xFFFFu, bin = (best >> 16) & 31u;
+            const bool obs = q_obs ? q_obs[(size_t)qf * cap + qi] != 0 : true;
+            if (obs && valid && myk == k) blocked = true;                  // later queries of this group see the claim
+            if (lane == 0) {
+                mrow[k] = qi;
+                if (obs) blk[k >> 5] |= 1u << (k & 31);
+                if (check_ori && bin != TK_NOBIN) { acc[nacc] = k | (bin << 16); hist[bin] += 1; }
+            }
+            ++nm;
+            if (check_ori && bin != TK_NOBIN) ++nacc;
+        }
+        key = nkey; cnt = ncnt;
+    }
+    __syncthreads();
+    if (check_ori) {
+        // ComputeThreeMaxima (ORBmatcher.cc:2870-2909) on the bin counts, then every assignment of the other bins is cleared (:2696-2707)
+        int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+        for (int i = 0; i < 30; ++i) {
+            const int sz = (int)hist[i];
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = i; }
+            else if (sz > max3) { max3 = sz; i3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) i3 = -1;
+        int pruned = 0;
+        for (int e = lane; e < nacc; e += 64) {
+            const unsigned int v = acc[e];
+            const int bin = (int)(v >> 16), k = (int)(v & 0xFFFFu);
+            if (bin != i1 && bin != i2 && bin != i3) { mrow[k] = -2; ++pruned; }      // ORBM_MATCH_PRUNED
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pruned += __shfl_xor(pruned, o);
+        nm -= pruned;
+    }
+    if (lane == 0) nmatches[pair] = nm;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_bow_transform: DBoW2 TemplatedVocabulary::transform (TemplatedVocabulary.h:1196-1262) for a batch of
 // descriptors.  One thread per descriptor walks the k-ary tree: at every level the child with the smallest
 // Hamming distance (first minimum, strict <) is taken; the node reached at level L-levelsup is recorded.

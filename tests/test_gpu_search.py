@@ -382,6 +382,68 @@ def test_device_resident_tracking_window_batch(pkg, oracle, synth):
             assert sec_d[p, q] == (int(rest.min()) if len(rest) else 256)
 
 
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_batched_search_by_projection_final_matches(pkg, oracle, synth, check_ori):
+    """M4 end to end on the device for a batch of frame pairs (claims in query order, TH_HIGH, rotation histogram + three-maxima
+    cull): the final match row and count of every pair equal orbm_search_by_projection_frame (single-frame host replay) AND the
+    oracle, entry for entry.  The batch holds an EMPTY frame (both as the searched and as the searching one), pairs whose searched
+    frame has 35 % / 97 % of its slots blocked (the second drives queries through all eight listed candidates into the in-place
+    rescan), queries without observations (their slot can be taken again), and a frame matched against itself (distance-0 ties)."""
+    import ctypes as C
+    NB = 10
+    imgs = [synth.gen_image(752, 480, 700 + i) for i in range(NB)]
+    imgs[9] = imgs[8]                                                          # pair 8 matches a frame against itself
+    imgs[3] = np.full((480, 752), 128, np.uint8)                               # no corner anywhere: an empty frame
+    ex = pkg.ORBextractor(1000, max_size=(752, 480), max_batch=NB)
+    res = ex.extract_batch(imgs, [(0, 1000)] * NB)
+    assert len(res[3][1]) == 0
+    m = pkg.ORBmatcher(0.9)
+    OM = oracle._oracle_matcher_class()()
+    L = pkg.lib()
+    r = ex.result_device(); cap = r["cap"]
+    gs = pkg.DeviceBuffer(NB * 3073 * 4); gi = pkg.DeviceBuffer(NB * cap * 4)
+    inv_w = np.float32(64) / np.float32(752); inv_h = np.float32(48) / np.float32(480)
+    assert L.orbm_grid_build_batch_async(m.h, r["kps"], r["counts"], NB, cap, 0.0, 0.0, float(inv_w), float(inv_h), gs.ptr, gi.ptr) == 0
+    rng = np.random.default_rng(11)
+    blocked = np.zeros((NB, cap), np.uint8); obs = np.ones((NB, cap), np.uint8)
+    blocked[1] = rng.random(cap) < 0.35
+    blocked[6] = rng.random(cap) < 0.97
+    obs[2] = rng.random(cap) < 0.5
+    obs[7] = 0
+    dblk = pkg.DeviceBuffer(NB * cap); dobs = pkg.DeviceBuffer(NB * cap)
+    dblk.upload(blocked); dobs.upload(obs)
+    NP = NB - 1
+    dm = pkg.DeviceBuffer(NP * cap * 4); dn = pkg.DeviceBuffer(NP * 4)
+    sf = ex.GetScaleFactors()
+    dx, dy, th = 2.0, -1.0, 15.0
+    for _ in (0,):                                                             # pair p: frame p+1 (queries) searches frame p
+        rc = L.orbm_search_by_projection_batch_async(m.h, r["kps"], r["desc"], r["counts"], cap, gs.ptr, gi.ptr, 0.0, 0.0, float(inv_w), float(inv_h),
+                                                     1, 0, NP, th, sf.ctypes.data_as(C.c_void_p), 8, dx, dy, dblk.ptr, dobs.ptr, int(check_ori),
+                                                     dm.ptr, dn.ptr)
+        assert rc == 0, L.orbm_last_error()
+    m.sync()
+    match = dm.download(np.int32, NP * cap).reshape(NP, cap); nm = dn.download(np.int32, NP)
+    saw_pruned = False
+    for p in range(NP):
+        (_, kq, dq), (_, kt, dt) = res[p + 1], res[p]
+        nq, nt = len(kq), len(kt)
+        args = dict(cur_blocked=blocked[p, :nt], scale_factors=sf, valid=np.ones(nq, np.uint8), u=kq["x"] + np.float32(dx), v=kq["y"] + np.float32(dy),
+                    invzc=np.zeros(nq, np.float32), octave=kq["octave"], angle=kq["angle"], qdesc=dq, mp_obs=obs[p + 1, :nq], th=th, check_ori=check_ori)
+        if nt == 0:
+            assert nm[p] == 0 and np.all(match[p] == -1)
+            continue
+        n_ref, m_ref = OM.SearchByProjectionFrame(pkg.FrameView(kt, dt, 752, 480, backend=OM), **args)
+        n_host, m_host = m.SearchByProjectionFrame(pkg.FrameView(kt, dt, 752, 480, backend=m), **args)
+        assert n_host == n_ref and np.array_equal(m_host, m_ref)
+        assert nm[p] == n_ref, (p, nm[p], n_ref)
+        assert np.array_equal(match[p, :nt], m_ref), (p, np.flatnonzero(match[p, :nt] != m_ref)[:10])
+        assert np.all(match[p, nt:] == -1)
+        saw_pruned = saw_pruned or bool((m_ref == -2).any())
+    assert nm[8] > 300                                                          # the self-pair matches well
+    if check_ori:
+        assert saw_pruned
+
+
 def test_window_capacity_overflow_is_retried(pkg, scene, monkeypatch):
     """Frame::GetFeaturesInArea is unbounded; the device windows have a default capacity.  A window that overflows it is run
     again with room for every keypoint of the frame (ORBM_WINDOW_CAP forces a tiny first capacity): same result as before."""
