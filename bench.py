@@ -65,8 +65,8 @@ def parse_args(argv=None):
                          "auto: graph from 64 frames per step on, eager below (a small step's graph is placed differently from one "
                          "instantiation to the next: 0.24 or 0.32 ms per 16-frame step, eager 0.245 every time)")
     ap.add_argument("--match", choices=["window", "knn2"], default="knn2",
-                    help="c2/c5 match leg: 'knn2' = dense brute-force 2-NN (Frame.cc:1440-1480); 'window' = the mono SearchByProjection "
-                         "window search of every keypoint in the previous frame (eager launch only)")
+                    help="c2/c5 match leg: 'knn2' = dense brute-force 2-NN (Frame.cc:1440-1480); 'window' = the monocular tracker's own "
+                         "matcher, SearchByProjection(frame, previous frame) with final matches on the device (Tracking.cc:3203-3211)")
     ap.add_argument("--cpu-sample", type=int, default=96, help="frames timed through the CPU oracle (0 = skip)")
     return ap.parse_args(argv)
 
@@ -187,9 +187,7 @@ class OrbWorkload:
             L.orbx_set_result_block(ex.h, blk)
             self.res.append(ex.result_device())
         L.orbx_set_result_block(ex.h, 0)
-        self.idx2 = pkg.DeviceBuffer(B * cap * 2 * 4); self.dist2 = pkg.DeviceBuffer(B * cap * 2 * 4)
         if args.match == "window":
-            self.gstart = pkg.DeviceBuffer(B * 3073 * 4); self.gidx = pkg.DeviceBuffer(B * cap * 4); self.sdist = pkg.DeviceBuffer(B * cap * 4)
             self.sf_host = ex.GetScaleFactors()
             self.inv_w = float(np.float32(64) / np.float32(W)); self.inv_h = float(np.float32(48) / np.float32(H))   # Frame.cc:401-402
         # ---- where the results land on the host: pinned, one block per array (reused every step, like a Frame's mvKeys)
@@ -197,9 +195,11 @@ class OrbWorkload:
         self.host_bytes = self.layout[4]
         if self.cfg == "c3":
             self._setup_c3()                                    # attaches the matcher's per-block outputs behind the block
+        else:
+            self._setup_match_outputs()                         # likewise: the match leg's results travel to the host with the block
         self.h_blk = [pkg.PinnedBuffer(self.host_bytes) for _ in range(self.nblk)]
         self.download = True
-        self.graph = (args.launch == "graph" or (args.launch == "auto" and B >= 64)) and args.match == "knn2"
+        self.graph = args.launch == "graph" or (args.launch == "auto" and B >= 64)
         self.nslots = 8
         self.captured = False
         self.measure_match = False
@@ -209,6 +209,30 @@ class OrbWorkload:
         assert L.orbm_set_stream(mt.h, L.orbx_stream(ex.h)) == 0
         L.orbx_set_stage_timing(ex.h, 0)
 
+    def _setup_match_outputs(self):
+        """Per result block the match leg's outputs (c2 / c5: 2-NN lists or SearchByProjection match rows of every frame against the
+        previous one; c4: 2-NN lists of left x right), attached to the block: ONE copy takes keypoints, descriptors, counts and
+        matches to the host."""
+        pkg, L, B, cap = self.pkg, self.L, self.B, self.cap
+        self.mo, self.mo_off = [], None
+        for blk in range(self.nblk):
+            if self.cfg in ("c2", "c5") and self.args.match == "window":
+                d = dict(match=pkg.DeviceBuffer(B * cap * 4), nm=pkg.DeviceBuffer(B * 4), gs=pkg.DeviceBuffer(B * 3073 * 4), gi=pkg.DeviceBuffer(B * cap * 4))
+                keys = ("match", "nm")
+            else:
+                rows = B if self.cfg in ("c2", "c5") else B // 2
+                d = dict(idx2=pkg.DeviceBuffer(rows * cap * 2 * 4), dist2=pkg.DeviceBuffer(rows * cap * 2 * 4))
+                keys = ("idx2", "dist2")
+            offs = {}
+            for key in keys:
+                o = C.c_size_t()
+                rc = L.orbx_block_attach(self.ex.h, blk, d[key].ptr, d[key].nbytes, C.byref(o))
+                assert rc == 0, rc
+                offs[key] = int(o.value)
+                self.host_bytes = max(self.host_bytes, offs[key] + ((d[key].nbytes + 255) & ~255))
+            self.mo_off = offs
+            self.mo.append(d)
+
     # ---- one step's kernels (what a graph slot holds): extraction into result block `blk` + the match leg on that block
     def _enqueue(self, blk):
         L, ex, mt, r, B, cap = self.L, self.ex, self.mt, self.res[blk], self.B, self.cap
@@ -217,22 +241,26 @@ class OrbWorkload:
         if self.measure_match:                                  # untimed eager pass of report(): stamps around the match leg
             L.orbx_mark(ex.h, 0)
         if self.cfg in ("c2", "c5"):
+            mo = self.mo[blk]
             if self.args.match == "window" and B > 1:
-                rc = L.orbm_grid_build_batch_async(mt.h, r["kps"], r["counts"], B, cap, 0.0, 0.0, self.inv_w, self.inv_h, self.gstart.ptr, self.gidx.ptr)
+                # the monocular tracker's own matcher (Tracking.cc:3203-3211): AssignFeaturesToGrid of every frame, then
+                # SearchByProjection(frame i, frame i-1, th = 15, mono) end to end on the device: final match rows + counts
+                rc = L.orbm_grid_build_batch_async(mt.h, r["kps"], r["counts"], B, cap, 0.0, 0.0, self.inv_w, self.inv_h, mo["gs"].ptr, mo["gi"].ptr)
                 assert rc == 0, rc
-                rc = L.orbm_track_window_batch_async(mt.h, r["kps"], r["desc"], r["counts"], cap, self.gstart.ptr, self.gidx.ptr,
-                                                     0.0, 0.0, self.inv_w, self.inv_h, 1, 0, B - 1, 15.0,
-                                                     self.sf_host.ctypes.data_as(C.c_void_p), 8, 0.0, 0.0,
-                                                     self.idx2.ptr, self.dist2.ptr, self.sdist.ptr)
-                assert rc == 0, rc
+                rc = L.orbm_search_by_projection_batch_async(mt.h, r["kps"], r["desc"], r["counts"], cap, mo["gs"].ptr, mo["gi"].ptr,
+                                                             0.0, 0.0, self.inv_w, self.inv_h, 1, 0, B - 1, 15.0,
+                                                             self.sf_host.ctypes.data_as(C.c_void_p), 8, 0.0, 0.0, None, None, 1,
+                                                             mo["match"].ptr, mo["nm"].ptr)
+                assert rc == 0, (rc, L.orbm_last_error())
             elif B > 1:          # dense 2-NN of frame i (query) against frame i-1 (train): B-1 pairs
                 rc = L.orbm_knn2_batch_async(mt.h, r["desc"] + cap * 32, cap, r["counts"] + 4, r["desc"], cap, r["counts"],
-                                             B - 1, cap, self.idx2.ptr + cap * 8, self.dist2.ptr + cap * 8)
+                                             B - 1, cap, mo["idx2"].ptr + cap * 8, mo["dist2"].ptr + cap * 8)
                 assert rc == 0, rc
         elif self.cfg == "c4":   # ComputeStereoFishEyeMatches: left descriptors (query) x right descriptors (train) of the same pair
             P = B // 2
+            mo = self.mo[blk]
             rc = L.orbm_knn2_batch_async(mt.h, r["desc"], cap, r["counts"], r["desc"] + P * cap * 32, cap, r["counts"] + 4 * P,
-                                         P, cap, self.idx2.ptr, self.dist2.ptr)
+                                         P, cap, mo["idx2"].ptr, mo["dist2"].ptr)
             assert rc == 0, rc
         else:
             self._enqueue_c3(blk)
@@ -579,6 +607,48 @@ def pin_to_gpu_numa_node(local_rank):
         return None
 
 
+def match_verify(wl, blk):
+    """Outside the timed region: the match leg's outputs of the last step, as they arrived in the pinned host block, against the
+    oracle on the same images (first and last pair of the batch)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orbref
+    B, cap = wl.B, wl.cap
+    hb = wl.h_blk[blk].bytes
+    off = wl.mo_off
+    ok = True
+
+    def feat(i):
+        return orbref.Extractor(wl.nF, 1.2, 8, 20, 7)(wl.host_imgs[i], wl.lap)
+    if wl.cfg in ("c2", "c5"):
+        if B < 2:
+            return True
+        for p in sorted({0, B - 2}):
+            nt, kt, dt, _ = feat(p); nq, kq, dq, _ = feat(p + 1)
+            if wl.args.match == "window":
+                OM = orbref._oracle_matcher_class()()
+                m_h = hb[off["match"]:off["match"] + 4 * B * cap].view(np.int32).reshape(B, cap)
+                n_h = hb[off["nm"]:off["nm"] + 4 * B].view(np.int32)
+                fv = wl.pkg.FrameView(kt, dt, wl.W, wl.H, backend=OM)
+                n_ref, m_ref = OM.SearchByProjectionFrame(fv, np.zeros(nt, np.uint8), wl.sf_host, np.ones(nq, np.uint8), kq["x"], kq["y"], np.zeros(nq, np.float32),
+                                                          kq["octave"], kq["angle"], dq, np.ones(nq, np.uint8), 15.0, check_ori=True)
+                ok = ok and int(n_h[p]) == n_ref and np.array_equal(m_h[p, :nt], m_ref)
+            else:
+                i_h = hb[off["idx2"]:off["idx2"] + 8 * B * cap].view(np.int32).reshape(B, cap, 2)
+                d_h = hb[off["dist2"]:off["dist2"] + 8 * B * cap].view(np.int32).reshape(B, cap, 2)
+                ri, rd = orbref.knn2(dq, dt)
+                ok = ok and np.array_equal(i_h[p + 1, :nq], ri) and np.array_equal(d_h[p + 1, :nq], rd)
+    elif wl.cfg == "c4":
+        P = B // 2
+        i_h = hb[off["idx2"]:off["idx2"] + 8 * P * cap].view(np.int32).reshape(P, cap, 2)
+        d_h = hb[off["dist2"]:off["dist2"] + 8 * P * cap].view(np.int32).reshape(P, cap, 2)
+        for p in sorted({0, P - 1}):
+            nl, kl, dl, _ = feat(p); nr, kr, dr, _ = feat(P + p)
+            ri, rd = orbref.knn2(dl, dr)
+            ok = ok and np.array_equal(i_h[p, :nl], ri) and np.array_equal(d_h[p, :nl], rd)
+    return bool(ok)
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -765,13 +835,14 @@ def report(wl, args, world, dt, dt_res, t_enq, gpu_wall, extra, total_kp, frames
             "c3": "%d stereo pairs (the stereo Frame constructor, Frame.cc:103-200, + what LocalMapping does with a new KeyFrame): ComputeStereoMatches and AssignFeaturesToGrid per pair, ComputeBoW buckets (synthetic k=10 L=3 vocabulary) and one SearchForTriangulation_ per pair "
                   "(its left image against the right image of the previous step as the neighbouring KeyFrame)" % (B // 2)}
     if args.match == "window":
-        legs["c2"] = legs["c5"] = "Frame grid build and SearchByProjection window match (th=15) of every keypoint in the previous frame"
+        legs["c2"] = legs["c5"] = ("AssignFeaturesToGrid + SearchByProjection(frame, previous frame, th=15, mono; ORBmatcher.cc:2469-2711) of every frame, "
+                                   "final match rows (claims, TH_HIGH, rotation-histogram cull) on the device")
     d2h = wl.host_bytes
     out = {
         "metric": "ORB extract+match frames/sec @%dx%d, %d feat" % (W, H, nF),
         "config": {"workload": (cname + ": " if named else "other size (not a named config): ") +
                                "%dx%d grayscale, %d features, 8 levels, scale 1.2, FAST 20/7; batch of %d frames/GPU/step resident in HBM; "
-                               "extract + %s; keypoints, descriptors and counts of every batch copied to pinned host memory inside the timed region"
+                               "extract + %s; keypoints, descriptors, counts AND the match leg's outputs of every batch copied to pinned host memory inside the timed region"
                                % (W, H, nF, B, legs[wl.cfg]),
                    "frames_per_step_per_gpu": B, "launch": "hipGraph replay (one hipGraphLaunch per step)" if wl.graph else "eager enqueue",
                    "keypoints_last_batch": total_kp, "result_bytes_to_host_per_step": d2h},
@@ -814,6 +885,8 @@ def report(wl, args, world, dt, dt_res, t_enq, gpu_wall, extra, total_kp, frames
         n = len(kps)
         ok = ok and n == int(n_pin[i]) and mono == int(m_pin[i]) and np.array_equal(kps.view(np.uint8).reshape(n, 28), k_pin[i, :n]) and np.array_equal(desc, d_pin[i, :n])
     out["host_copy_matches_device"] = ok
+    if wl.cfg != "c3":
+        out["match_leg_matches_oracle"] = match_verify(wl, blk)
     if wl.cfg == "c3":
         ok3, nst, ntri = c3_verify(wl, blk)
         out["stereo_and_triangulation_match_oracle"] = ok3

@@ -1099,6 +1099,31 @@ __global__ __launch_bounds__(256) void k_track_window(const KpIn* __restrict__ k
 // ------------------------------------------------------------------------------------------------
 #define TK_K 8
 #define TK_NOBIN 31
+// wave-wide minimum of a 32-bit key by DPP (six v_min_u32 with data movement folded in; the result of a full reduction sits in lane 63)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ int wave_excl_scan(int v, int* total) {           // exclusive prefix sum over the 64 lanes
+    int s = v;
+    s += __builtin_amdgcn_update_dpp(0, s, 0x111, 0xf, 0xf, true);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x112, 0xf, 0xf, true);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xf, true);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xf, true);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x142, 0xa, 0xf, false);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x143, 0xc, 0xf, false);
+    *total = __builtin_amdgcn_readlane(s, 63);
+    return s - v;
+}
+// The window's grid columns are flattened into ONE candidate list (column starts / lengths loaded by one lane each, prefix sum across
+// lanes), so that a window of up to 64 candidates costs four dependent round trips (cell ranges, indices, keypoints, descriptors)
+// whatever its shape -- the per-column loop of k_track_window pays them per column -- and the eight best come out of eight DPP
+// minimum reductions of a 32-bit key (distance << 16 | position), already in rank order.
 __global__ __launch_bounds__(256) void k_track_topk(const KpIn* __restrict__ kps, const uint8_t* __restrict__ desc,
                                                     const int* __restrict__ counts, int cap, const int* __restrict__ grid_start,
                                                     const int* __restrict__ grid_idx, float min_x, float min_y, float inv_w, float inv_h,
@@ -1116,10 +1141,10 @@ __global__ __launch_bounds__(256) void k_track_topk(const KpIn* __restrict__ kps
     const int* gi = grid_idx + (size_t)tf * cap;
     const float x = kq.x + dx, y = kq.y + dy, r = th * st.sf[kq.octave];
     const int minLevel = kq.octave - 1, maxLevel = kq.octave + 1;
-    const u64 INV = ~0ull;
-    u64 top[TK_K];
+    const unsigned INV = 0xFFFFFFFFu;
+    unsigned topKey[TK_K], topPay[TK_K];                                   // (distance << 16 | position) ascending; payload = bin << 16 | keypoint
 #pragma unroll
-    for (int i = 0; i < TK_K; ++i) top[i] = INV;
+    for (int i = 0; i < TK_K; ++i) { topKey[i] = INV; topPay[i] = INV; }
     int cnt = 0;
     const int nMinCellX = max(0, (int)floorf((x - min_x - r) * inv_w));
     const int nMaxCellX = min(63, (int)ceilf((x - min_x + r) * inv_w));
@@ -1131,44 +1156,77 @@ __global__ __launch_bounds__(256) void k_track_topk(const KpIn* __restrict__ kps
         const u64 a[4] = {(u64)qlo.x | ((u64)qlo.y << 32), (u64)qlo.z | ((u64)qlo.w << 32),
                           (u64)qhi.x | ((u64)qhi.y << 32), (u64)qhi.z | ((u64)qhi.w << 32)};
         const unsigned long long lt = (1ull << lane) - 1ull;
-        for (int ix = nMinCellX; ix <= nMaxCellX; ++ix) {
-            const int j0 = gs[ix * 48 + nMinCellY], j1 = gs[ix * 48 + nMaxCellY + 1];
-            for (int jb = j0; jb < j1; jb += 64) {
-                const int j = jb + lane;
-                bool ok = false;
-                int k = 0;
-                float ang = 0.f;
-                if (j < j1) {
-                    k = gi[j];
-                    const KpIn kp = kt[k];
-                    ok = !(kp.octave < minLevel) && !(kp.octave > maxLevel);   // bCheckLevels is true here (maxLevel >= 0)
-                    if (!(fabsf(kp.x - x) < r && fabsf(kp.y - y) < r)) ok = false;
-                    ang = kp.angle;
-                }
-                const unsigned long long bal = __ballot(ok);
-                u64 key = INV;
-                if (ok) {
-                    const int pos = cnt + __popcll(bal & lt);
-                    const uint4* tp = (const uint4*)(dt + (size_t)k * 32);
-                    const uint4 lo = tp[0], hi = tp[1];
-                    const int d = ham256(a, (u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
-                                         (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32));
-                    float rot = kq.angle - ang;
-                    if (rot < 0.0f) rot += 360.0f;
-                    int bin = (int)roundf(rot * factor);
-                    if (bin == 30) bin = 0;
-                    if (bin < 0 || bin >= 30) bin = TK_NOBIN;
-                    key = ((u64)d << 44) | ((u64)pos << 24) | ((u64)bin << 16) | (u64)k;
-                }
-                cnt += __popcll(bal);
-                if (bal == 0) continue;
-                for (int rnd = 0; rnd < TK_K; ++rnd) {           // merge this chunk into the running top-K (keys are unique: position)
-                    const u64 m = wave_min_u64(key);
-                    if (m >= top[TK_K - 1]) break;
-                    if (key == m) key = INV;
-                    u64 c = m;
+        const int ncols = nMaxCellX - nMinCellX + 1;                       // <= 64 (the grid has 64 columns)
+        int cj0 = 0, clen = 0;
+        if (lane < ncols) {
+            const int ix = nMinCellX + lane;
+            cj0 = gs[ix * 48 + nMinCellY];
+            clen = gs[ix * 48 + nMaxCellY + 1] - cj0;
+        }
+        int total;
+        const int coff = wave_excl_scan(clen, &total);
+        bool first = true;
+        for (int base = 0; base < total; base += 64) {
+            const int t = base + lane;
+            // the lane's column: the last one whose offset is <= t (columns in ascending order, empty ones share an offset)
+            int myj0 = 0, myoff = 0;
+            for (int c = 0; c < ncols; ++c) {
+                const int oc = __builtin_amdgcn_readlane(coff, c), jc = __builtin_amdgcn_readlane(cj0, c);
+                if (t >= oc) { myoff = oc; myj0 = jc; }
+            }
+            bool ok = false;
+            int k = 0;
+            float ang = 0.f;
+            if (t < total) {
+                k = gi[myj0 + (t - myoff)];
+                const KpIn kp = kt[k];
+                ok = !(kp.octave < minLevel) && !(kp.octave > maxLevel);   // bCheckLevels is true here (maxLevel >= 0)
+                if (!(fabsf(kp.x - x) < r && fabsf(kp.y - y) < r)) ok = false;
+                ang = kp.angle;
+            }
+            const unsigned long long bal = __ballot(ok);
+            if (bal == 0) continue;
+            unsigned key = INV, pay = INV;
+            if (ok) {
+                const int pos = cnt + __popcll(bal & lt);
+                const uint4* tp = (const uint4*)(dt + (size_t)k * 32);
+                const uint4 lo = tp[0], hi = tp[1];
+                const int d = ham256(a, (u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
+                                     (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32));
+                float rot = kq.angle - ang;
+                if (rot < 0.0f) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == 30) bin = 0;
+                if (bin < 0 || bin >= 30) bin = TK_NOBIN;
+                key = ((unsigned)d << 16) | (unsigned)pos;                   // positions < 65536 (cap)
+                pay = ((unsigned)bin << 16) | (unsigned)k;
+            }
+            cnt += __popcll(bal);
+            if (first) {
+                // first chunk: the minima come out in rank order
 #pragma unroll
-                    for (int i = 0; i < TK_K; ++i) { const u64 t = top[i]; const bool sw = c < t; top[i] = sw ? c : t; c = sw ? t : c; }
+                for (int i = 0; i < TK_K; ++i) {
+                    const unsigned m = wave_min_u32(key);
+                    if (m == INV) break;
+                    const int src = __ffsll((long long)__ballot(key == m)) - 1;     // keys are unique (position)
+                    topKey[i] = m; topPay[i] = (unsigned)__builtin_amdgcn_readlane((int)pay, src);
+                    if (lane == src) key = INV;
+                }
+                first = false;
+            } else {
+                for (int rnd = 0; rnd < TK_K; ++rnd) {                     // later chunks (windows of more than 64 grid entries): insertion
+                    const unsigned m = wave_min_u32(key);
+                    if (m >= topKey[TK_K - 1]) break;                      // INV included
+                    const int src = __ffsll((long long)__ballot(key == m)) - 1;
+                    unsigned ck = m, cp = (unsigned)__builtin_amdgcn_readlane((int)pay, src);
+                    if (lane == src) key = INV;
+#pragma unroll
+                    for (int i = 0; i < TK_K; ++i) {
+                        const bool sw = ck < topKey[i];
+                        const unsigned tk = topKey[i], tp2 = topPay[i];
+                        topKey[i] = sw ? ck : tk; topPay[i] = sw ? cp : tp2;
+                        ck = sw ? tk : ck; cp = sw ? tp2 : cp;
+                    }
                 }
             }
         }
@@ -1178,7 +1236,7 @@ __global__ __launch_bounds__(256) void k_track_topk(const KpIn* __restrict__ kps
         out_cnt[o] = cnt;
 #pragma unroll
         for (int i = 0; i < TK_K; ++i)
-            out_keys[o * TK_K + i] = top[i] == INV ? 0xFFFFFFFFu : ((unsigned)(top[i] >> 44) << 21) | (unsigned)(top[i] & 0x1FFFFFu);
+            out_keys[o * TK_K + i] = topKey[i] == INV ? 0xFFFFFFFFu : ((topKey[i] >> 16) << 21) | (topPay[i] & 0x1FFFFFu);
     }
 }
 
