@@ -223,6 +223,9 @@ class OrbWorkload:
                 rows = B if self.cfg in ("c2", "c5") else B // 2
                 d = dict(idx2=pkg.DeviceBuffer(rows * cap * 2 * 4), dist2=pkg.DeviceBuffer(rows * cap * 2 * 4))
                 keys = ("idx2", "dist2")
+                if self.cfg == "c4":                                # ComputeStereoFishEyeMatches keeps the Lowe-ratio survivors (Frame.cc:1465)
+                    d["good"] = pkg.DeviceBuffer(rows * cap)
+                    keys = ("idx2", "dist2", "good")
             offs = {}
             for key in keys:
                 o = C.c_size_t()
@@ -259,8 +262,8 @@ class OrbWorkload:
         elif self.cfg == "c4":   # ComputeStereoFishEyeMatches: left descriptors (query) x right descriptors (train) of the same pair
             P = B // 2
             mo = self.mo[blk]
-            rc = L.orbm_knn2_batch_async(mt.h, r["desc"], cap, r["counts"], r["desc"] + P * cap * 32, cap, r["counts"] + 4 * P,
-                                         P, cap, mo["idx2"].ptr, mo["dist2"].ptr)
+            rc = L.orbm_knn2_ratio_batch_async(mt.h, r["desc"], cap, r["counts"], r["desc"] + P * cap * 32, cap, r["counts"] + 4 * P,
+                                               P, 0.7, mo["idx2"].ptr, mo["dist2"].ptr, mo["good"].ptr)
             assert rc == 0, rc
         else:
             self._enqueue_c3(blk)
@@ -645,7 +648,9 @@ def match_verify(wl, blk):
         for p in sorted({0, P - 1}):
             nl, kl, dl, _ = feat(p); nr, kr, dr, _ = feat(P + p)
             ri, rd = orbref.knn2(dl, dr)
-            ok = ok and np.array_equal(i_h[p, :nl], ri) and np.array_equal(d_h[p, :nl], rd)
+            g_h = hb[off["good"]:off["good"] + P * cap].reshape(P, cap)
+            want = np.array([1 if (a >= 0 and b >= 0 and float(np.float32(a)) < float(np.float32(b)) * 0.7) else 0 for a, b in rd.tolist()], np.uint8)
+            ok = ok and np.array_equal(i_h[p, :nl], ri) and np.array_equal(d_h[p, :nl], rd) and np.array_equal(g_h[p, :nl], want)
     return bool(ok)
 
 
@@ -831,7 +836,7 @@ def report(wl, args, world, dt, dt_res, t_enq, gpu_wall, extra, total_kp, frames
     named = (W, H, nF) == (cw, ch, cnf)
     legs = {"c2": "dense 2-NN Hamming match (int8 MFMA) of every frame against the previous one",
             "c5": "dense 2-NN Hamming match (int8 MFMA) of every frame against the previous one",
-            "c4": "%d fisheye stereo pairs: brute-force 2-NN of left x right descriptors per pair (ComputeStereoFishEyeMatches)" % (B // 2),
+            "c4": "%d fisheye stereo pairs: brute-force 2-NN of left x right descriptors per pair + Lowe ratio 0.7 in the kernel's epilogue (ComputeStereoFishEyeMatches, Frame.cc:1458-1465)" % (B // 2),
             "c3": "%d stereo pairs (the stereo Frame constructor, Frame.cc:103-200, + what LocalMapping does with a new KeyFrame): ComputeStereoMatches and AssignFeaturesToGrid per pair, ComputeBoW buckets (synthetic k=10 L=3 vocabulary) and one SearchForTriangulation_ per pair "
                   "(its left image against the right image of the previous step as the neighbouring KeyFrame)" % (B // 2)}
     if args.match == "window":

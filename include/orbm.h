@@ -52,6 +52,12 @@ void orbm_three_maxima(const int* bin_sizes, int L, int* ind3);
 int orbm_knn2_batch(orbm_t*, int space, const uint8_t* q, int q_stride, const int32_t* nq,
                     const uint8_t* t, int t_stride, const int32_t* nt, int npairs,
                     int32_t* idx2, int32_t* dist2);
+/* M16 with the reference's acceptance test in the kernel's epilogue: good[npairs][q_stride] (device) = 1 where the query has two
+ * neighbours and `(*it)[0].distance < (*it)[1].distance * ratio` holds as Frame.cc:1465 evaluates it (float distances, double
+ * product; the reference's ratio is 0.7), else 0.  idx2 / dist2 as orbm_knn2_batch_async.  Device pointers, enqueue only. */
+int orbm_knn2_ratio_batch_async(orbm_t*, const uint8_t* q, int q_stride, const int32_t* nq,
+                                const uint8_t* t, int t_stride, const int32_t* nt, int npairs, double ratio,
+                                int32_t* idx2, int32_t* dist2, uint8_t* good);
 /* async form (device pointers only, no sync) -- the timed body of bench.py */
 int orbm_knn2_batch_async(orbm_t*, const uint8_t* q, int q_stride, const int32_t* nq,
                           const uint8_t* t, int t_stride, const int32_t* nt, int npairs, int max_nt,

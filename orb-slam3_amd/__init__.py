@@ -33,7 +33,7 @@ EXPORTS = [
     "orbx_host_alloc", "orbx_host_free", "orbx_set_result_block", "orbx_mark", "orbx_mark_elapsed_ms",
     # include/orbm.h
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_sync", "orbm_stream", "orbm_set_stream", "orbm_hamming",
-    "orbm_three_maxima", "orbm_knn2_batch", "orbm_knn2_batch_async", "orbm_last_timing",
+    "orbm_three_maxima", "orbm_knn2_batch", "orbm_knn2_batch_async", "orbm_knn2_ratio_batch_async", "orbm_last_timing",
     "orbm_stereo_batch_async", "orbm_bow_nodes_batch_async", "orbm_triangulation_batch_async",
 ]
 
@@ -117,6 +117,7 @@ def lib():
         L.orbm_three_maxima.argtypes = [vp, ci, vp]
         L.orbm_knn2_batch.argtypes = [vp, ci, vp, ci, vp, vp, ci, vp, ci, vp, vp]
         L.orbm_knn2_batch_async.argtypes = [vp, vp, ci, vp, vp, ci, vp, ci, ci, vp, vp]
+        L.orbm_knn2_ratio_batch_async.argtypes = [vp, vp, ci, vp, vp, ci, vp, ci, C.c_double, vp, vp, vp]
         L.orbm_last_timing.argtypes = [vp, vp]
         L.orbm_stereo_batch_async.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp, ci, C.c_float, C.c_float, vp, vp, vp, vp]
         L.orbm_bow_nodes_batch_async.argtypes = [vp, vp, vp, ci, ci, vp]

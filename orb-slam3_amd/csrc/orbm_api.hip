@@ -160,9 +160,23 @@ void orbm_three_maxima(const int* sz, int L, int* ind3) {
     ind3[0] = i1; ind3[1] = i2; ind3[2] = i3;
 }
 
+static int knn2_launch(orbm_t* m, const uint8_t* q, int q_stride, const int32_t* nq, const uint8_t* t, int t_stride,
+                       const int32_t* nt, int npairs, int32_t* idx2, int32_t* dist2, double ratio, uint8_t* good);
+
 int orbm_knn2_batch_async(orbm_t* m, const uint8_t* q, int q_stride, const int32_t* nq, const uint8_t* t, int t_stride,
                           const int32_t* nt, int npairs, int max_nt, int32_t* idx2, int32_t* dist2) {
     (void)max_nt;
+    return knn2_launch(m, q, q_stride, nq, t, t_stride, nt, npairs, idx2, dist2, 0.0, nullptr);
+}
+
+int orbm_knn2_ratio_batch_async(orbm_t* m, const uint8_t* q, int q_stride, const int32_t* nq, const uint8_t* t, int t_stride,
+                                const int32_t* nt, int npairs, double ratio, int32_t* idx2, int32_t* dist2, uint8_t* good) {
+    if (!good) return ORBM_E_INVALID;
+    return knn2_launch(m, q, q_stride, nq, t, t_stride, nt, npairs, idx2, dist2, ratio, good);
+}
+
+static int knn2_launch(orbm_t* m, const uint8_t* q, int q_stride, const int32_t* nq, const uint8_t* t, int t_stride,
+                       const int32_t* nt, int npairs, int32_t* idx2, int32_t* dist2, double ratio, uint8_t* good) {
     if (!m || !q || !t || !nq || !nt || !idx2 || !dist2 || npairs < 1 || q_stride < 1 || t_stride < 1) return ORBM_E_INVALID;
     if (t_stride >= (1 << 22)) { set_merr("knn2: more than 2^22 train descriptors per pair"); return ORBM_E_INVALID; }
     MHIPCHK(hipSetDevice(m->device));
@@ -171,9 +185,9 @@ int orbm_knn2_batch_async(orbm_t* m, const uint8_t* q, int q_stride, const int32
     // matrix-core kernel unless the train set is beyond its 19-bit row field (or ORBM_KNN2_VALU asks for the popcount kernel: A/B)
     const bool forceValu = getenv("ORBM_KNN2_VALU") != nullptr;   // read per call: tests flip it
     if (t_stride <= KM_MAX_NT && !forceValu)
-        hipLaunchKernelGGL(k_knn2_mfma, dim3((q_stride + 255) / 256, npairs), dim3(256), 0, m->stream, q, q_stride, nq, t, t_stride, nt, idx2, dist2);
+        hipLaunchKernelGGL(k_knn2_mfma, dim3((q_stride + 255) / 256, npairs), dim3(256), 0, m->stream, q, q_stride, nq, t, t_stride, nt, idx2, dist2, ratio, good);
     else
-        hipLaunchKernelGGL(k_knn2, dim3((q_stride + 63) / 64, npairs), dim3(256), 0, m->stream, q, q_stride, nq, t, t_stride, nt, idx2, dist2);
+        hipLaunchKernelGGL(k_knn2, dim3((q_stride + 63) / 64, npairs), dim3(256), 0, m->stream, q, q_stride, nq, t, t_stride, nt, idx2, dist2, ratio, good);
     MHIPCHK(rec_time(m, m->e1));
     MHIPCHK(hipGetLastError());
     m->timed = true;

@@ -47,7 +47,7 @@ __device__ __forceinline__ void top2_insert(int d, int j, int& d0, int& j0, int&
 #define KNN_CHUNK 1024
 __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int q_stride, const int* __restrict__ nq,
                                               const uint8_t* __restrict__ t, int t_stride, const int* __restrict__ nt,
-                                              int* __restrict__ idx2, int* __restrict__ dist2) {
+                                              int* __restrict__ idx2, int* __restrict__ dist2, double ratio, uint8_t* __restrict__ good) {
     __shared__ __attribute__((aligned(16))) u64 tr[KNN_CHUNK * 4];
     __shared__ int mrg[4][64][4];
     const int pair = blockIdx.y;
@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int
         const bool h0 = k0 != 0xFFFFFFFFu, h1 = k1 != 0xFFFFFFFFu;
         idx2[o] = h0 ? (int)(k0 & 0x3FFFFFu) : -1; idx2[o + 1] = h1 ? (int)(k1 & 0x3FFFFFu) : -1;
         dist2[o] = h0 ? (int)(k0 >> 22) : -1; dist2[o + 1] = h1 ? (int)(k1 >> 22) : -1;
+        if (good) good[o >> 1] = (h0 && h1 && (double)(float)(int)(k0 >> 22) < (double)(float)(int)(k1 >> 22) * ratio) ? 1 : 0;   // Frame.cc:1465
     }
 }
 
@@ -131,7 +132,7 @@ typedef int km_i32x16 __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t* __restrict__ q, int q_stride, const int* __restrict__ nq,
                                                    const uint8_t* __restrict__ t, int t_stride, const int* __restrict__ nt,
-                                                   int* __restrict__ idx2, int* __restrict__ dist2) {
+                                                   int* __restrict__ idx2, int* __restrict__ dist2, double ratio, uint8_t* __restrict__ good) {
 #if __HIP_DEVICE_COMPILE__
     const int pair = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -237,8 +238,11 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t* __restrict__ q
         const size_t o = ((size_t)pair * q_stride + qi) * 2;
         const bool h0 = f0 != 0xFFFFFFFFu, h1 = f1 != 0xFFFFFFFFu;
         idx2[o] = h0 ? (int)(f0 & 0x7FFFFu) : -1; idx2[o + 1] = h1 ? (int)(f1 & 0x7FFFFu) : -1;
-        dist2[o] = h0 ? (int)(f0 >> 19) - 256 + pqs : -1;
-        dist2[o + 1] = h1 ? (int)(f1 >> 19) - 256 + pqs : -1;
+        const int d0 = h0 ? (int)(f0 >> 19) - 256 + pqs : -1, d1 = h1 ? (int)(f1 >> 19) - 256 + pqs : -1;
+        dist2[o] = d0;
+        dist2[o + 1] = d1;
+        // Lowe's ratio as Frame.cc:1465 writes it: two neighbours and (float)d0 < (float)d1 * 0.7 evaluated in double
+        if (good) good[(size_t)pair * q_stride + qi] = (h0 && h1 && (double)(float)d0 < (double)(float)d1 * ratio) ? 1 : 0;
     }
 #endif
 }

@@ -109,3 +109,41 @@ def test_knn2_rejects_train_sets_beyond_the_packed_index_range(pkg):
     rc = m.L.orbm_knn2_batch_async(m.h, one.ptr, 1, one.ptr, one.ptr, 1 << 22, one.ptr, 1, 1 << 22, one.ptr, one.ptr)
     assert rc < 0
     assert b"2^22" in m.L.orbm_last_error()
+
+
+@pytest.mark.parametrize("valu", [False, True])
+def test_knn2_lowe_ratio_in_the_epilogue(pkg, oracle, monkeypatch, valu):
+    """M16 'knn2 + ratio': good[q] as Frame.cc:1465 decides it -- two neighbours and (float)d0 < (float)d1 * 0.7 in double -- written
+    by the kernel itself (both kernels), incl. queries with fewer than two train rows and exact-boundary distances (7 vs 10)."""
+    import ctypes as C
+    if valu:
+        monkeypatch.setenv("ORBM_KNN2_VALU", "1")
+    rng = np.random.default_rng(2024)
+    nqs, nts = [300, 5, 64, 1], [400, 1, 0, 2]
+    qs, ts = 320, 416
+    P = len(nqs)
+    q = rng.integers(0, 256, (P, qs, 32), dtype=np.uint8); t = rng.integers(0, 256, (P, ts, 32), dtype=np.uint8)
+    # boundary: query 0 of pair 0 (all zeros) at distance 7 from train row 0 and 10 from row 1: 7 < 10 * 0.7 is FALSE (the double product is 7.0)
+    q[0, 0] = 0; t[0, 0] = 0; t[0, 0, 0] = 0x7F; t[0, 1] = 0; t[0, 1, 0] = 0xFF; t[0, 1, 1] = 0x03
+    # query 1 (all ones) at distances 6 and 10 from rows 2 and 3: accepted
+    q[0, 1] = 0xFF; t[0, 2] = 0xFF; t[0, 2, 0] = 0x03; t[0, 3] = 0xFF; t[0, 3, 0] = 0x00; t[0, 3, 1] = 0xFC
+    dq, dt = pkg.DeviceBuffer(q.nbytes), pkg.DeviceBuffer(t.nbytes)
+    dq.upload(q); dt.upload(t)
+    nq = np.array(nqs, np.int32); nt = np.array(nts, np.int32)
+    dnq, dnt = pkg.DeviceBuffer(4 * P), pkg.DeviceBuffer(4 * P)
+    dnq.upload(nq); dnt.upload(nt)
+    di, dd, dg = pkg.DeviceBuffer(P * qs * 8), pkg.DeviceBuffer(P * qs * 8), pkg.DeviceBuffer(P * qs)
+    m = pkg.ORBmatcher()
+    rc = m.L.orbm_knn2_ratio_batch_async(m.h, dq.ptr, qs, dnq.ptr, dt.ptr, ts, dnt.ptr, P, 0.7, di.ptr, dd.ptr, dg.ptr)
+    assert rc == 0, m.L.orbm_last_error()
+    m.sync()
+    idx = di.download(np.int32, P * qs * 2).reshape(P, qs, 2); dist = dd.download(np.int32, P * qs * 2).reshape(P, qs, 2)
+    good = dg.download(np.uint8, P * qs).reshape(P, qs)
+    for i in range(P):
+        ri, rd = oracle.knn2(q[i, :nqs[i]], t[i, :nts[i]])
+        assert np.array_equal(idx[i, :nqs[i]], ri) and np.array_equal(dist[i, :nqs[i]], rd)
+        want = np.array([1 if (a >= 0 and b >= 0 and float(np.float32(a)) < float(np.float32(b)) * 0.7) else 0 for a, b in rd.tolist()], np.uint8)
+        assert np.array_equal(good[i, :nqs[i]], want), i
+    assert dist[0, 0].tolist() == [7, 10] and good[0, 0] == 0
+    assert dist[0, 1].tolist() == [6, 10] and good[0, 1] == 1
+    assert good[1].sum() == 0 and good[2].sum() == 0                  # one / zero train rows: never two neighbours
