@@ -16,6 +16,13 @@
 
 using namespace orbmk;
 
+// A/B switches and test knobs exist only in the -DORBX_AB build (see orbx_api.hip)
+#ifdef ORBX_AB
+static inline const char* ab_env(const char* name) { return getenv(name); }
+#else
+static inline const char* ab_env(const char*) { return nullptr; }
+#endif
+
 static thread_local std::string g_merr;
 static void set_merr(const char* fmt, ...) {
     char buf[512];
@@ -183,7 +190,7 @@ static int knn2_launch(orbm_t* m, const uint8_t* q, int q_stride, const int32_t*
     m->gridFirst = false;
     MHIPCHK(rec_time(m, m->e0));
     // matrix-core kernel unless the train set is beyond its 19-bit row field (or ORBM_KNN2_VALU asks for the popcount kernel: A/B)
-    const bool forceValu = getenv("ORBM_KNN2_VALU") != nullptr;   // read per call: tests flip it
+    const bool forceValu = ab_env("ORBM_KNN2_VALU") != nullptr;   // read per call: tests flip it
     if (t_stride <= KM_MAX_NT && !forceValu)
         hipLaunchKernelGGL(k_knn2_mfma, dim3((q_stride + 255) / 256, npairs), dim3(256), 0, m->stream, q, q_stride, nq, t, t_stride, nt, idx2, dist2, ratio, good);
     else
@@ -311,7 +318,7 @@ int window_pass(orbm* m, const orbm_frame_t* f, int nq, const float* qx, const f
     // `cap` in: capacity of a window on the device; out: row stride of idx / dist (= the longest candidate list, >= 1)
     cnt.assign(nq, 0);
     if (nq == 0 || f->n == 0) return ORBM_OK;
-    if (const char* e = retry ? nullptr : getenv("ORBM_WINDOW_CAP")) cap = std::max(1, std::min(cap, atoi(e)));   // test knob: a small first capacity forces the retry below
+    if (const char* e = retry ? nullptr : ab_env("ORBM_WINDOW_CAP")) cap = std::max(1, std::min(cap, atoi(e)));   // test knob: a small first capacity forces the retry below
     MHIPCHK(hipSetDevice(m->device));
     DevBuf dk, dd, du, dgs, dgi, dqx, dqy, dqr, dmin, dmax, dqu, dqe, dqd, dcnt, didx, ddist, dovf, dpack;
     arena_reset(m);
@@ -400,7 +407,7 @@ int window_topk_pass(orbm* m, const orbm_dframe* df, bool stereo_gate, int nq, c
     UP(dqd, qdesc, (size_t)32 * nq);
     AL(dcnt, sizeof(int) * nq); AL(dkeys, sizeof(unsigned int) * (size_t)nq * WT_K);
     static const bool prof = getenv("ORBM_PROFILE") != nullptr;
-    static const bool copies = getenv("ORBM_TOPK_COPIES") != nullptr;     // A/B: staged copies instead of zero-copy
+    static const bool copies = ab_env("ORBM_TOPK_COPIES") != nullptr;     // A/B: staged copies instead of zero-copy
     auto T = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = prof ? T() : 0;
     if (prof) MHIPCHK(rec_time(m, m->e0));                       // a latency path: no event records unless someone is looking

@@ -37,6 +37,16 @@ static const int8_t kPattern[1024] = {
 #include "orb_pattern.inc"
 };
 
+// A/B switches (first-generation kernels, scheduling variants, test knobs) exist only in the -DORBX_AB build (liborbslam3_amd_ab.so, what
+// tests/ab runs against); in the product library they read as unset and the kernels behind them are not compiled in.
+#ifdef ORBX_AB
+static inline const char* ab_env(const char* name) { return getenv(name); }
+#define AB_LAUNCH(...) hipLaunchKernelGGL(__VA_ARGS__)
+#else
+static inline const char* ab_env(const char*) { return nullptr; }
+#define AB_LAUNCH(...) ((void)0)                              /* (the flag that guards the call is never set in this build) */
+#endif
+
 static inline int cv_round_f(float v) { return (int)lrintf(v); }
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -520,7 +530,7 @@ static int build_geometry(orbx* o, int w, int h) {
             }
             if (o->f3QcapForce > 0) G.qcap = std::min(G.qcap, align_up(o->f3QcapForce, 64));
             G.lds = (size_t)2 * G.tile + (size_t)(F3_NT / 64) * G.qcap * 2;
-            if (const char* e = getenv("ORBX_FAST_LDSPAD")) G.lds += (size_t)atoi(e);   // experiment: occupancy sensitivity
+            if (const char* e = ab_env("ORBX_FAST_LDSPAD")) G.lds += (size_t)atoi(e);   // experiment: occupancy sensitivity
             if (G.lds > 160 * 1024 - 256) { set_err("FAST strip needs %zu B of LDS", G.lds); return ORBX_E_UNSUPPORTED; }
             maxLds = std::max(maxLds, G.lds);
             o->f3g.push_back(G);
@@ -574,12 +584,16 @@ static int build_geometry(orbx* o, int w, int h) {
         HIPCHK(hipFuncSetAttribute((const void*)k_fast4<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
         HIPCHK(hipFuncSetAttribute((const void*)k_fast4<176>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
         HIPCHK(hipFuncSetAttribute((const void*)k_fast4<208>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
+#ifdef ORBX_AB
         HIPCHK(hipFuncSetAttribute((const void*)k_fast3<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
         HIPCHK(hipFuncSetAttribute((const void*)k_fast3<176>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
         HIPCHK(hipFuncSetAttribute((const void*)k_fast3<208>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
+#endif
     }
     if (ensure(&o->dOvfList, &o->capOvfList, (size_t)g.totalCells * B)) return ORBX_E_HIP;
+#ifdef ORBX_AB
     HIPCHK(hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->qtLds));
+#endif
     HIPCHK(hipFuncSetAttribute((const void*)k_quadtree2<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->qt2Lds));
     HIPCHK(hipFuncSetAttribute((const void*)k_quadtree2<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->qt2Lds));
     o->curW = w; o->curH = h;
@@ -633,7 +647,8 @@ static void dl_worker(orbx* o) {
             if (o->dlKernel) {
                 const size_t n16 = o->blockBytes / 16;               // blockBytes is a multiple of 256
                 const unsigned grid = (unsigned)std::min<size_t>(o->dlGrid, (n16 + 255) / 256);
-                hipLaunchKernelGGL(k_copy_out, dim3(grid), dim3(256), 0, o->stream3, (v4u_t*)r.host, (const v4u_t*)o->rb[r.block].base, n16);
+                AB_LAUNCH(k_copy_out, dim3(grid), dim3(256), 0, o->stream3, (v4u_t*)r.host, (const v4u_t*)o->rb[r.block].base, n16);
+                (void)grid;
                 e = hipGetLastError();
             } else
                 e = hipMemcpyAsync(r.host, o->rb[r.block].base, o->blockBytes, hipMemcpyDeviceToHost, o->stream3);
@@ -694,23 +709,23 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     orbx* o = new orbx;
     o->nfeatures = nfeatures; o->nlevels = nlevels; o->iniTh = ini_th; o->minTh = min_th; o->device = device_id;
     o->maxW = max_w; o->maxH = max_h; o->maxBatch = max_batch;
-    o->fastV1 = getenv("ORBX_FAST_V1") != nullptr;
-    o->qtV1 = getenv("ORBX_QT_V1") != nullptr;
+    o->fastV1 = ab_env("ORBX_FAST_V1") != nullptr;
+    o->qtV1 = ab_env("ORBX_QT_V1") != nullptr;
     // default: the matrix-core blur (k_blur3) directly behind the resize chain, i.e. beside FAST (which is VALU/LDS-bound, while
     // k_blur3 is memory + MFMA).  A/B switches: ORBX_BLUR_V2 = the VALU blur (k_blur2) beside the quadtree as before;
     // ORBX_BLUR_LATE = k_blur3 but beside the quadtree.
-    o->blurV2 = getenv("ORBX_BLUR_V2") != nullptr;
-    o->odV1 = getenv("ORBX_OD_V1") != nullptr;
-    if (const char* e = getenv("ORBX_FAST_QCAP")) o->f3QcapForce = atoi(e);
-    o->f3NoFixedPitch = getenv("ORBX_FAST_PITCH0") != nullptr;
-    o->fastV3 = getenv("ORBX_FAST_V3") != nullptr;
-    if (const char* e = getenv("ORBX_QT_WIDE")) o->qtWideForce = atoi(e) != 0 ? 1 : 0;
-    o->blurEarly = !o->blurV2 && getenv("ORBX_BLUR_LATE") == nullptr;
-    o->blurTiled = !o->blurV2 && !o->odV1 && getenv("ORBX_BLUR_ROWMAJOR") == nullptr;
-    o->dlKernel = getenv("ORBX_DL_KERNEL") != nullptr;          // A/B: results-to-host copy by k_copy_out instead of the copy engine
-    if (const char* e = getenv("ORBX_DL_GRID")) o->dlGrid = std::max(1, atoi(e));
-    if (const char* e = getenv("ORBX_ONE_GRAPH")) o->oneOff = atoi(e) == 0;   // A/B: single-frame calls stay eager
-    o->serial = getenv("ORBX_SERIAL") != nullptr;            // A/B switch: simple per-cell reference kernel
+    o->blurV2 = ab_env("ORBX_BLUR_V2") != nullptr;
+    o->odV1 = ab_env("ORBX_OD_V1") != nullptr;
+    if (const char* e = ab_env("ORBX_FAST_QCAP")) o->f3QcapForce = atoi(e);
+    o->f3NoFixedPitch = ab_env("ORBX_FAST_PITCH0") != nullptr;
+    o->fastV3 = ab_env("ORBX_FAST_V3") != nullptr;
+    if (const char* e = ab_env("ORBX_QT_WIDE")) o->qtWideForce = atoi(e) != 0 ? 1 : 0;
+    o->blurEarly = !o->blurV2 && ab_env("ORBX_BLUR_LATE") == nullptr;
+    o->blurTiled = !o->blurV2 && !o->odV1 && ab_env("ORBX_BLUR_ROWMAJOR") == nullptr;
+    o->dlKernel = ab_env("ORBX_DL_KERNEL") != nullptr;          // A/B: results-to-host copy by k_copy_out instead of the copy engine
+    if (const char* e = ab_env("ORBX_DL_GRID")) o->dlGrid = std::max(1, atoi(e));
+    if (const char* e = ab_env("ORBX_ONE_GRAPH")) o->oneOff = atoi(e) == 0;   // A/B: single-frame calls stay eager
+    o->serial = ab_env("ORBX_SERIAL") != nullptr;            // A/B switch: simple per-cell reference kernel
     o->scaleFactor = scale_factor;                              // double member initialised from float (ORBextractor.h:96)
     const int L = nlevels;
     o->sf.resize(L); o->sig2.resize(L); o->invsf.resize(L); o->invsig2.resize(L); o->nfeat.resize(L);
@@ -910,8 +925,8 @@ static int extract_batch_async_impl(orbx_t* o, const uint8_t* const* imgs, int i
     if (o->fastV1) {
         HIPCHK(hipStreamWaitEvent(st, dep_ev(o, 8), 0));
         STAGE_EV(1, st);
-        hipLaunchKernelGGL(k_fast, dim3(g.totalCells, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dCells,
-                           o->dCandCnt, o->dCandEnt, o->dErr);
+        AB_LAUNCH(k_fast, dim3(g.totalCells, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dCells,
+                  o->dCandCnt, o->dCandEnt, o->dErr);
         STAGE_EV(10, st);
     } else {
         // every group waits only for the pyramid levels it reads: the fine levels start while the coarse ones are still
@@ -930,9 +945,13 @@ static int extract_batch_async_impl(orbx_t* o, const uint8_t* const* imgs, int i
                 hipLaunchKernelGGL(kern, dim3((unsigned)G.nstrips, nimg), dim3(F3_NT), G.lds, st, g, o->dL0Ptr, l0pitch, o->dPyr,
                                    o->dAux, o->dF4Items, o->dStrips + G.strip0, o->dCandCnt, o->dCandEnt, o->dErr, G.tile, G.qcap, o->dOvf, o->dOvfList);
             } else {
+#ifdef ORBX_AB
                 auto kern = G.pitch == 176 ? k_fast3<176> : G.pitch == 208 ? k_fast3<208> : k_fast3<0>;
                 hipLaunchKernelGGL(kern, dim3((unsigned)G.nstrips, nimg), dim3(F3_NT), G.lds, st, g, o->dL0Ptr, l0pitch, o->dPyr,
                                    o->dCells, o->dStrips + G.strip0, o->dCandCnt, o->dCandEnt, o->dErr, G.tile, G.qcap, o->dOvf, o->dOvfList);
+#else
+                set_err("FAST group outside k_fast4's field limits (cells wider than 125 px or taller than 127 rows)"); return ORBX_E_UNSUPPORTED;
+#endif
             }
         }
         if (first) {                                             // single-level extractor
@@ -951,8 +970,8 @@ static int extract_batch_async_impl(orbx_t* o, const uint8_t* const* imgs, int i
     if (!o->serial && !o->blurEarly) HIPCHK(hipStreamWaitEvent(s1, dep_ev(o, 2), 0));
     STAGE_EV(11, s1);
     if (o->blurV2)
-        hipLaunchKernelGGL(k_blur2, dim3((unsigned)(o->tiles.size() + 3) / 4, nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
-                           o->dTiles, (int)o->tiles.size(), o->blurSel);
+        AB_LAUNCH(k_blur2, dim3((unsigned)(o->tiles.size() + 3) / 4, nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
+                  o->dTiles, (int)o->tiles.size(), o->blurSel);
     else {
         // big batches: workgroups walk B3_CHUNK tiles (prologue amortised); small ones: one tile per workgroup (8x the workgroups,
         // an eighth of the latency -- the single-frame path)
@@ -963,8 +982,8 @@ static int extract_batch_async_impl(orbx_t* o, const uint8_t* const* imgs, int i
     }
     HIPCHK(rec_ev(o, 9, s1, true));                              // blur ready
     if (o->qtV1)
-        hipLaunchKernelGGL(k_quadtree, dim3(nimg, g.nlevels), dim3(256), o->qtLds, st, g, o->dCells, o->dCandCnt, o->dCandEnt,
-                           o->dKpNode, o->dSel, o->dSelCnt, o->dErr);
+        AB_LAUNCH(k_quadtree, dim3(nimg, g.nlevels), dim3(256), o->qtLds, st, g, o->dCells, o->dCandCnt, o->dCandEnt,
+                  o->dKpNode, o->dSel, o->dSelCnt, o->dErr);
     else {
         Geom g2 = g; g2.nodeCap = o->qt2Cap; g2.sortCap = o->qt2Sort;
         // few workgroups (small batches, the single-frame call): the kernel's time is one workgroup's latency, and 1024 threads walk
@@ -989,8 +1008,8 @@ static int extract_batch_async_impl(orbx_t* o, const uint8_t* const* imgs, int i
     HIPCHK(hipStreamWaitEvent(st, dep_ev(o, 9), 0));
     STAGE_EV(5, st);
     if (o->odV1)
-        hipLaunchKernelGGL(k_orient_desc, dim3((g.kpCap + 3) / 4, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
-                           o->dWork, o->dN, o->dKps, o->dDesc, o->dPattern, o->umax);
+        AB_LAUNCH(k_orient_desc, dim3((g.kpCap + 3) / 4, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
+                  o->dWork, o->dN, o->dKps, o->dDesc, o->dPattern, o->umax);
     else
         hipLaunchKernelGGL(k_orient_desc2, dim3((g.kpCap + 15) / 16, nimg), dim3(256), 0, st, g, o->dL0Ptr, l0pitch, o->dPyr, o->dBlur,
                            o->dWork, o->dN, o->dKps, o->dDesc, o->dPattern, o->dOdW);

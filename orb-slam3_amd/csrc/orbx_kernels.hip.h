@@ -24,6 +24,7 @@ typedef uint16_t u16;
 typedef uint8_t u8;
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef short ss2 __attribute__((ext_vector_type(2)));
 struct RzTab { int s; short a0, a1; };                     // source index + two Q11 taps (8 bytes)
 
 struct LevelDesc {                                         // one pyramid level of the current geometry
@@ -275,10 +276,10 @@ __device__ __forceinline__ int fast_score16(const u8* t, int p) {
     return max(v - amin, bmax - v) - 1;
 }
 
+#ifdef ORBX_AB   /* A/B reference, not in the product library */
 // Two pixels per lane: the same network on packed 16-bit halves (v_pk_min/max_u16 have no 3-input form, so 47 packed ops
 // per side serve two pixels: 47 per pixel against 72).  The ring bytes of pixel A land in the low halves, those of
 // pixel B in the high halves (ds_read_u8_d16 / _d16_hi).  Returns the two scores as signed 16-bit halves.
-typedef short ss2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ ss2 fast_score16x2(const u8* ta, const u8* tb, int p) {
     // (an 8-byte-per-row variant with unaligned ds_read_b64 -- 7 LDS reads per pixel instead of 17 -- is bit-exact but 1.7x
     // slower on gfx950: unaligned LDS reads are split.  The scattered byte reads bound this phase, not the min/max network.)
@@ -308,6 +309,7 @@ __device__ __forceinline__ ss2 fast_score16x2(const u8* ta, const u8* tb, int p)
     const ss2 d1 = __builtin_bit_cast(ss2, v - amin), d2 = __builtin_bit_cast(ss2, bmax - v);   // |.| <= 255: exact as signed 16-bit
     return __builtin_elementwise_max(d1, d2) - ss2{1, 1};
 }
+#endif  /* ORBX_AB */
 
 // ------------------------------------------------------------------------------------------------
 // k_fast: one workgroup per FAST cell (the sub-image the reference hands to cv::FAST).
@@ -388,11 +390,14 @@ __device__ __forceinline__ void fast_cell_block(const Geom& g, const u8* const* 
     if (tid == 0) candCnt[(size_t)frame * g.totalCells + c.cnt] = (u32)base;
 }
 
+#ifdef ORBX_AB   /* k_fast: A/B reference, not in the product library */
 __global__ __launch_bounds__(256) void k_fast(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
                                               const CellInfo* __restrict__ cells, u32* candCnt, u32* candEnt,
                                               int* err) {
     fast_cell_block(g, l0, l0pitch, pyr, cells, candCnt, candEnt, err, blockIdx.x, blockIdx.y);
 }
+
+#endif  /* ORBX_AB */
 
 // k_fast_fix: cells whose quick-reject survivors did not fit k_fast3's bounded LDS queue (rare: the queue holds 500+
 // of a cell's ~1400 pixels; a dense-corner texture is needed) are redone here by the per-cell kernel body, which has no
@@ -413,6 +418,11 @@ __global__ __launch_bounds__(256) void k_fast_fix(Geom g, const u8* const* l0, i
 
 struct StripInfo { short level, ncell, x0, y0, w, h, xal, lp; int cell0; };   // lp = LDS tile pitch in bytes
 
+#define F3_NT 256
+#ifndef F3_XCD
+#define F3_XCD 1                                            // neighbouring strips (they share 6 columns and whole lines) on one XCD
+#endif
+#ifdef ORBX_AB   /* k_fast3: A/B reference (round 2's FAST), not in the product library */
 // ------------------------------------------------------------------------------------------------
 // k_fast3: strip tile shared by the workgroup, but every FAST cell is processed by ONE wavefront with no
 // workgroup barrier after the tile load (k_fast2 spent its time parked at 7 barriers with 2 WGs/CU).
@@ -424,12 +434,8 @@ struct StripInfo { short level, ncell, x0, y0, w, h, xal, lp; int cell0; };   //
 // No atomics, no bitmap: all counts live in wave-uniform registers.  The queue is bounded (occupancy); a cell whose
 // survivors do not fit is handed to k_fast_fix through a global list.
 // ------------------------------------------------------------------------------------------------
-#define F3_NT 256
 #ifndef F3_ASM_SCAN
 #define F3_ASM_SCAN 1
-#endif
-#ifndef F3_XCD
-#define F3_XCD 1                                            // neighbouring strips (they share 6 columns and whole lines) on one XCD
 #endif
 // PITCH > 0: every strip of the launch uses this LDS tile pitch (bytes), so that row offsets become instruction immediates
 // (18 address adds per scored pixel pair, and the +-3-row reads of the quick test); PITCH == 0: per-strip pitch st.lp (wide cells).
@@ -688,6 +694,8 @@ __global__ __launch_bounds__(F3_NT) void k_fast3(Geom g, const u8* const* l0, in
         if (lane == 0) candCnt[(size_t)frame * g.totalCells + cell.cnt] = (u32)n3;
     }
 }
+
+#endif  /* ORBX_AB */
 
 // ------------------------------------------------------------------------------------------------
 // k_fast4: k_fast3 on an instruction diet (round 3).  Same algorithm, same order, same outputs; what changed:
@@ -1062,6 +1070,7 @@ __device__ __forceinline__ int qt_quadrant(short4 r, int x, int y) {
     return x < mx ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
 }
 
+#ifdef ORBX_AB   /* A/B reference, not in the product library */
 __global__ __launch_bounds__(256) void k_quadtree(Geom g, const CellInfo* __restrict__ cells,
                                                   const u32* __restrict__ candCnt, const u32* __restrict__ candEnt,
                                                   u16* kpNode, u32* selOut, u32* selCnt, int* err) {
@@ -1289,6 +1298,8 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const CellInfo* __rest
     }
     if (tid == 0) selCnt[frame * g.nlevels + level] = (u32)min(nsel, L.selCap);
 }
+
+#endif  /* ORBX_AB */
 
 // ------------------------------------------------------------------------------------------------
 // k_quadtree2: the same DistributeOctTree, with the list surgery itself data-parallel.
@@ -2002,6 +2013,7 @@ struct BlurTask { short level, g0, y0, pad; };            // g0 = first dword co
 
 struct BlurSel { u32 selB[12], selC[12]; };               // per level: right-edge fix-up selectors
 
+#ifdef ORBX_AB   /* A/B reference, not in the product library */
 __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int l0pitch, const u8* pyr, u8* blr,
                                                const BlurTask* __restrict__ tasks, int ntasks, BlurSel bs) {
     const int lane = threadIdx.x & 63;
@@ -2090,6 +2102,7 @@ __global__ __launch_bounds__(256) void k_blur2(Geom g, const u8* const* l0, int 
         }
     }
 }
+#endif  /* ORBX_AB */
 
 // ------------------------------------------------------------------------------------------------
 // k_orient_desc: one wavefront per keypoint.
@@ -2120,6 +2133,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 
 struct Umax { int v[16]; };
 
+#ifdef ORBX_AB   /* A/B reference, not in the product library */
 __global__ __launch_bounds__(256) void k_orient_desc(Geom g, const u8* const* l0, int l0pitch, const u8* pyr,
                                                      const u8* blr, const KpWork* __restrict__ work,
                                                      const int* __restrict__ nOut, KpOut* kps, u8* desc,
@@ -2170,6 +2184,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(Geom g, const u8* const* l0
     if ((lane & 7) == 0) ((u32*)(desc + row * 32))[lane >> 3] = word;
     if (lane == 0) kps[row].angle = angle;
 }
+#endif  /* ORBX_AB */
 
 // ------------------------------------------------------------------------------------------------
 // k_orient_desc2: FOUR keypoints per wavefront (16 lanes each) -- same arithmetic as k_orient_desc, a quarter of
@@ -2369,10 +2384,12 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
 // copy stream.  hipMemcpyAsync does the same job through the runtime's copy path, whose calls stall the enqueueing thread for
 // several milliseconds every ~10 copies on the runtime bench.py runs on; a launch does not.  A few workgroups saturate the link.
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+#ifdef ORBX_AB   /* A/B reference, not in the product library */
 __global__ __launch_bounds__(256) void k_copy_out(v4u_t* __restrict__ dst, const v4u_t* __restrict__ src, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
         __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
+#endif  /* ORBX_AB */
 
 // k_fetch_one: the single-frame call's results in ONE piece -- header (n, mono, error flag, pad) + n keypoints + n descriptors, packed,
 // written straight into pinned host memory (five synchronous device-to-host copies of a few bytes to a few KB each cost the caller

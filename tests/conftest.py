@@ -10,6 +10,10 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# tests/ab needs the -DORBX_AB build of the library (ORB_LIB): tests/test_ab_child.py runs it in a child process
+collect_ignore = [] if os.environ.get("ORB_AB_CHILD") == "1" else ["ab"]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     try:                                                    # property tests explore the same examples on every run

@@ -20,9 +20,9 @@ def test_knn2_random(pkg, oracle, nq, nt):
 
 
 @pytest.mark.parametrize("nq,nt", [(31, 31), (32, 32), (33, 33), (63, 65), (255, 95), (256, 96), (257, 97), (1000, 1000), (1, 4100)])
-def test_knn2_tile_edges_and_both_kernels(pkg, oracle, monkeypatch, nq, nt):
+def test_knn2_tile_edges(pkg, oracle, nq, nt):
     # k_knn2_mfma works on 32 x 32 tiles, 64 queries per wave, 256 per workgroup, train tiles walked last to first with a
-    # ragged last tile; k_knn2 (ORBM_KNN2_VALU) is the popcount kernel it replaced.  Both must equal the oracle.
+    # ragged last tile (the popcount kernel it replaced: tests/ab).
     rng = np.random.default_rng(nq * 31 + nt)
     q, t = _rand_desc(rng, nq), _rand_desc(rng, nt)
     q[0] = 0; q[-1] = 255                                        # popcount 0 / 256 queries
@@ -31,11 +31,8 @@ def test_knn2_tile_edges_and_both_kernels(pkg, oracle, monkeypatch, nq, nt):
         t[nt - 3] = t[5]                                         # equal distances far apart: lower index first
     ridx, rdist = oracle.knn2(q, t)
     m = pkg.ORBmatcher()
-    for force in (False, True):
-        if force:
-            monkeypatch.setenv("ORBM_KNN2_VALU", "1")
-        idx, dist = m.knn2(q, t)
-        assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), "valu" if force else "mfma"
+    idx, dist = m.knn2(q, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
     assert rdist.min() == 0
     # the extreme distances themselves: two train rows, all ones and all zeros
     t2 = np.stack([np.full(32, 255, np.uint8), np.zeros(32, np.uint8)])
@@ -111,13 +108,10 @@ def test_knn2_rejects_train_sets_beyond_the_packed_index_range(pkg):
     assert b"2^22" in m.L.orbm_last_error()
 
 
-@pytest.mark.parametrize("valu", [False, True])
-def test_knn2_lowe_ratio_in_the_epilogue(pkg, oracle, monkeypatch, valu):
+def test_knn2_lowe_ratio_in_the_epilogue(pkg, oracle):
     """M16 'knn2 + ratio': good[q] as Frame.cc:1465 decides it -- two neighbours and (float)d0 < (float)d1 * 0.7 in double -- written
-    by the kernel itself (both kernels), incl. queries with fewer than two train rows and exact-boundary distances (7 vs 10)."""
+    by the kernel itself, incl. queries with fewer than two train rows and exact-boundary distances (7 vs 10)."""
     import ctypes as C
-    if valu:
-        monkeypatch.setenv("ORBM_KNN2_VALU", "1")
     rng = np.random.default_rng(2024)
     nqs, nts = [300, 5, 64, 1], [400, 1, 0, 2]
     qs, ts = 320, 416
@@ -146,4 +140,4 @@ def test_knn2_lowe_ratio_in_the_epilogue(pkg, oracle, monkeypatch, valu):
         assert np.array_equal(good[i, :nqs[i]], want), i
     assert dist[0, 0].tolist() == [7, 10] and good[0, 0] == 0
     assert dist[0, 1].tolist() == [6, 10] and good[0, 1] == 1
-    assert good[1].sum() == 0 and good[2].sum() == 0                  # one / zero train rows: never two neighbours
+    assert good[1, :nqs[1]].sum() == 0 and good[2, :nqs[2]].sum() == 0  # one / zero train rows: never two neighbours

@@ -444,22 +444,6 @@ def test_batched_search_by_projection_final_matches(pkg, oracle, synth, check_or
         assert saw_pruned
 
 
-def test_window_capacity_overflow_is_retried(pkg, scene, monkeypatch):
-    """Frame::GetFeaturesInArea is unbounded; the device windows have a default capacity.  A window that overflows it is run
-    again with room for every keypoint of the frame (ORBM_WINDOW_CAP forces a tiny first capacity): same result as before."""
-    rng = np.random.default_rng(5)
-    kr = scene["kr"]
-    views = [pkg.FrameView(kr, scene["dr"], 752, 480, backend=b) for b in (scene["m"], scene["OM"])]
-    n, u, v = _queries(scene, rng)
-    args = dict(cur_blocked=rng.random(len(kr)) < 0.05, scale_factors=scene["sf"], valid=rng.random(n) < 0.85, u=u, v=v,
-                invzc=rng.uniform(0.05, 1.0, n), octave=scene["kl"]["octave"], angle=scene["kl"]["angle"], qdesc=scene["dl"],
-                mp_obs=rng.random(n) < 0.9, th=30, forward=False, backward=False, mbf=47.9, check_ori=True)
-    n_ref, m_ref = scene["OM"].SearchByProjectionFrame(views[1], **args)
-    monkeypatch.setenv("ORBM_WINDOW_CAP", "4")
-    n_gpu, m_gpu = scene["m"].SearchByProjectionFrame(views[0], **args)
-    assert n_gpu == n_ref and np.array_equal(m_gpu, m_ref) and n_ref > 50
-
-
 def test_pruned_slots_are_marked(pkg, scene):
     """M4 / M5 write into an existing mvpMapPoints: a slot that was assigned and then culled by the rotation-consistency check
     comes back as -2 (the reference NULLs it, ORBmatcher.cc:2700-2708), distinct from -1 = never touched; product == oracle."""
