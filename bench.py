@@ -67,6 +67,10 @@ def parse_args(argv=None):
     ap.add_argument("--match", choices=["window", "knn2"], default="knn2",
                     help="c2/c5 match leg: 'knn2' = dense brute-force 2-NN (Frame.cc:1440-1480); 'window' = the monocular tracker's own "
                          "matcher, SearchByProjection(frame, previous frame) with final matches on the device (Tracking.cc:3203-3211)")
+    ap.add_argument("--texture", choices=["dense", "sparse", "lowcontrast", "mixed"], default="dense",
+                    help="synthetic input class (orb-slam3_amd/synth.py): dense = SURVEY 8(d)'s generator (the headline; ~6 %% of the level-0 "
+                         "pixels are FAST corners), sparse = camera-like density (~2 %%), lowcontrast = corners mostly below iniThFAST "
+                         "(per-cell threshold retry), mixed = the three classes side by side in every batch")
     ap.add_argument("--cpu-sample", type=int, default=96, help="frames timed through the CPU oracle (0 = skip)")
     return ap.parse_args(argv)
 
@@ -172,7 +176,8 @@ class OrbWorkload:
             lefts = [p[0] for p in pairs]; rights = [p[1] for p in pairs]
             self.host_imgs = [lefts[i % len(lefts)] for i in range(B // 2)] + [rights[i % len(rights)] for i in range(B // 2)]
         else:
-            base = [synth.gen_image(W, H, 1000 * rank + 1 + i) for i in range(nd)]
+            kinds = {"dense": ("textured",), "sparse": ("sparse",), "lowcontrast": ("lowcontrast",), "mixed": ("textured", "sparse", "lowcontrast")}[args.texture]
+            base = [synth.gen_image(W, H, 1000 * rank + 1 + i, kinds[i % len(kinds)]) for i in range(nd)]
             self.host_imgs = [base[i % nd] for i in range(B)]
         self.dev = pkg.DeviceBuffer(stride * H * B)
         padded = np.zeros((H, stride), np.uint8)
@@ -846,9 +851,9 @@ def report(wl, args, world, dt, dt_res, t_enq, gpu_wall, extra, total_kp, frames
     out = {
         "metric": "ORB extract+match frames/sec @%dx%d, %d feat" % (W, H, nF),
         "config": {"workload": (cname + ": " if named else "other size (not a named config): ") +
-                               "%dx%d grayscale, %d features, 8 levels, scale 1.2, FAST 20/7; batch of %d frames/GPU/step resident in HBM; "
+                               "%dx%d grayscale (synthetic, texture class '%s', %d distinct frames per rank), %d features, 8 levels, scale 1.2, FAST 20/7; batch of %d frames/GPU/step resident in HBM; "
                                "extract + %s; keypoints, descriptors, counts AND the match leg's outputs of every batch copied to pinned host memory inside the timed region"
-                               % (W, H, nF, B, legs[wl.cfg]),
+                               % (W, H, args.texture, max(1, min(args.distinct, B)), nF, B, legs[wl.cfg]),
                    "frames_per_step_per_gpu": B, "launch": "hipGraph replay (one hipGraphLaunch per step)" if wl.graph else "eager enqueue",
                    "keypoints_last_batch": total_kp, "result_bytes_to_host_per_step": d2h},
         "value_device_resident": frames / dt_res, "ms_per_step_device_resident": dt_res / args.steps * 1e3,

@@ -3,6 +3,9 @@
 gen_image(w, h, seed): 8-octave value noise (mean 110, sigma ~45) + w*h/600 axis-aligned
 rectangles (3..40 px, contrast +-30..120) + w*h/1500 small blobs + N(0,2) pixel noise, clipped to u8.
 Pure numpy, deterministic for a given (w, h, seed, numpy version's PCG64 stream).
+kind = "textured" (above: SURVEY 8(d)'s generator; ~6 % of the level-0 pixels are FAST-20 corners, 10 % over the pyramid),
+"sparse" (camera-like corner density: ~1-2 % at level 0 -- smooth shading, a tenth of the rectangles, half the pixel noise),
+"lowcontrast" (corners mostly in the [minTh, iniTh) band: the per-cell threshold retry), "constant" (no corner at all).
 """
 import numpy as np
 
@@ -38,6 +41,31 @@ def gen_image(w, h, seed, kind="textured"):
             x = int(rng.integers(0, max(1, w - rw))); y = int(rng.integers(0, max(1, h - rh)))
             img[y:y + rh, x:x + rw] += float(rng.integers(9, 17)) * (1 if rng.random() < 0.5 else -1)
         img += rng.normal(0, 0.7, img.shape)
+        return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    if kind == "sparse":
+        # smooth shading (the fine octaves of the value noise damped) under a few objects: corners sit where rectangle edges meet,
+        # not all over the texture -- the corner density of camera imagery rather than of SURVEY 8(d)'s stress pattern
+        rng2 = np.random.default_rng(seed + 104729)
+        smooth = np.zeros((h, w), np.float64)
+        amp = 1.0
+        for o in range(5):
+            gw = max(2, (w >> (7 - o)) + 2); gh = max(2, (h >> (7 - o)) + 2)
+            smooth += amp * _upsample(rng2.standard_normal((gh, gw)), w, h)
+            amp *= 0.5
+        smooth = (smooth - smooth.mean()) / (smooth.std() + 1e-9)
+        img = 115 + 30 * smooth + 3.0 * img
+        for _ in range(max(1, w * h // 2500)):
+            rw = int(rng.integers(6, 61)); rh = int(rng.integers(6, 61))
+            x = int(rng.integers(0, max(1, w - rw))); y = int(rng.integers(0, max(1, h - rh)))
+            c = float(rng.integers(30, 101)) * (1 if rng.random() < 0.5 else -1)
+            img[y:y + rh, x:x + rw] += c
+        for _ in range(max(1, w * h // 4000)):
+            r = int(rng.integers(1, 4))
+            x = int(rng.integers(r, w - r)); y = int(rng.integers(r, h - r))
+            c = float(rng.integers(40, 121)) * (1 if rng.random() < 0.5 else -1)
+            yy, xx = np.mgrid[-r:r + 1, -r:r + 1]
+            img[y - r:y + r + 1, x - r:x + r + 1] += c * (xx * xx + yy * yy <= r * r)
+        img += rng.normal(0, 1.0, img.shape)
         return np.clip(np.rint(img), 0, 255).astype(np.uint8)
     img = 110 + 45 * img
     for _ in range(max(1, w * h // 600)):

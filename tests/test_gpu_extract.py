@@ -16,6 +16,8 @@ CASES = [
     (421, 307, 500, 6, (0, 0), "textured"),          # odd sizes, ragged last cells
     (752, 480, 5000, 9, (0, 1000), "textured"),      # the initialisation extractor (5 * nFeatures, Tracking.cc:1113): > 512 nodes per level -> four fused quadtree iterations
     (2400, 420, 1500, 11, (0, 0), "textured"),       # wide frame: six quadtree roots per level
+    (752, 480, 1000, 41, (0, 1000), "sparse"),       # camera-like corner density (~2 % of the level-0 pixels; "textured" is ~6 %)
+    (1920, 1080, 4000, 42, (0, 0), "sparse"),
 ]
 
 
@@ -92,6 +94,25 @@ def test_large_batch_paths(pkg, oracle, synth, nframes):
         mono, kps, desc = res[i]
         assert len(kps) == n_ref and mono == mono_ref, i
         assert kps.tobytes() == kps_ref.tobytes() and np.array_equal(desc, desc_ref), i
+
+
+def test_mixed_texture_batch(pkg, oracle, synth):
+    """One batch of 66 DISTINCT frames of three texture classes side by side (dense / sparse / low contrast): per-cell ini->min threshold
+    retries and queue overflows (k_fast_fix) of some frames next to dense frames that need neither, every frame equal to the oracle."""
+    kinds = ("textured", "sparse", "lowcontrast")
+    imgs = [synth.gen_image(752, 480, 4000 + i, kinds[i % 3]) for i in range(66)]
+    ex = pkg.ORBextractor(1000, max_size=(752, 480), max_batch=len(imgs))
+    res = ex.extract_batch(imgs, [(0, 1000)] * len(imgs))
+    ref = oracle.Extractor(1000)
+    ns = {k: [] for k in kinds}
+    for i, img in enumerate(imgs):
+        n_ref, kps_ref, desc_ref, mono_ref = ref(img, (0, 1000))
+        mono, kps, desc = res[i]
+        assert len(kps) == n_ref and mono == mono_ref, i
+        assert kps.tobytes() == kps_ref.tobytes() and np.array_equal(desc, desc_ref), i
+        ns[kinds[i % 3]].append(n_ref)
+    assert min(ns["textured"]) >= 1000 and min(ns["sparse"]) >= 900
+    ex.close()
 
 
 def test_idempotent_and_geometry_switch(pkg, synth):

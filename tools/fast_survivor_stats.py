@@ -4,7 +4,8 @@ import sys, numpy as np, importlib
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle')
 import orbref
 synth = importlib.import_module("orb-slam3_amd.synth")
-img = synth.gen_image(752,480,1)
+kind = sys.argv[1] if len(sys.argv) > 1 else 'textured'
+img = synth.gen_image(752,480,1,kind)
 ref = orbref.Extractor(1000)
 ref(img,(0,1000))
 ring = [(0,3),(1,3),(2,2),(3,1),(3,0),(3,-1),(2,-2),(1,-3),(0,-3),(-1,-3),(-2,-2),(-3,-1),(-3,0),(-3,1),(-2,2),(-1,3)]
