@@ -281,25 +281,14 @@ class OrbWorkload:
     MB = MBF / 435.2046959714599                                # Examples/Stereo/EuRoC.yaml:9,28
 
     def _setup_c3(self):
-        import tempfile
         np, pkg, L, B, cap = self.np, self.pkg, self.L, self.B, self.cap
         P = B // 2
-        rng = np.random.default_rng(4242)
-        # synthetic k = 10, L = 3 vocabulary in DBoW2's text format (ORBvoc.txt is a missing blob in the reference snapshot)
-        lines = ["10 3 0 0"]
-        frontier, nid = [(0, 0)], 0
-        while frontier:
-            pid, lvl = frontier.pop(0)
-            for _ in range(10):
-                nid += 1
-                leaf = lvl + 1 == 3
-                lines.append("%d %d %s %r" % (pid, 1 if leaf else 0, " ".join(map(str, rng.integers(0, 256, 32))), float(rng.uniform(0.1, 9.0))))
-                if not leaf:
-                    frontier.append((nid, lvl + 1))
-        self.voc_path = os.path.join(tempfile.mkdtemp(prefix="orbvoc"), "voc.txt")
-        open(self.voc_path, "w").write("\n".join(lines) + "\n")
-        self.voc = pkg.ORBVocabulary(self.mt, self.voc_path)
-        self.levelsup = 1                                       # node level 2 of 3: 100 buckets (ORBvoc: level 2 of 6 with levelsup 4)
+        # a seeded vocabulary of ORBvoc's shape: k = 10, L = 6 (1 111 111 nodes, 35.6 MB of node descriptors), used as Frame::ComputeBoW
+        # uses the real one: levelsup = 4, i.e. the 100 nodes of tree level 2 are the FeatureVector buckets (Frame.cc:905-918).
+        # ORBvoc.txt itself is a missing blob in the reference snapshot.
+        self.voc_tree = importlib.import_module("orb-slam3_amd.synth").gen_vocabulary(10, 6, seed=7)
+        self.voc = pkg.ORBVocabulary(self.mt, self.voc_tree)
+        self.levelsup = 4
         self.F12 = np.array([0, 0, 0, 0, 0, 0.11, 0, -0.11, 0], np.float32)    # a fixed small sideways motion between identical pinhole cameras
         self.ep = (1.0e4, 240.0)
         self.sf = self.ex.GetScaleFactors(); self.sig2 = self.ex.GetScaleSigmaSquares()
@@ -503,7 +492,7 @@ def cpu_baseline(wl, args):
         P = max(2, min(half, ns // 8))
         refs = [orbref.Extractor(nF, 1.2, 8, 20, 7) for _ in range(2)]
         OM = orbref._oracle_matcher_class()()
-        voc = orbref.Vocabulary(wl.voc_path)
+        voc = orbref.Vocabulary(wl.voc_tree)
         nmatch = []
         tc = time.perf_counter()
         for p in range(P):
@@ -557,7 +546,7 @@ def c3_verify(wl, blk):
     gs_h = hb[off["gs"]:off["gs"] + 4 * P * 3073].view(np.int32).reshape(P, 3073)
     gi_h = hb[off["gi"]:off["gi"] + 4 * P * cap].view(np.int32).reshape(P, cap)
     OM = orbref._oracle_matcher_class()()
-    voc = orbref.Vocabulary(wl.voc_path)
+    voc = orbref.Vocabulary(wl.voc_tree)
     ok = True
     cache = {}
 
@@ -842,7 +831,7 @@ def report(wl, args, world, dt, dt_res, t_enq, gpu_wall, extra, total_kp, frames
     legs = {"c2": "dense 2-NN Hamming match (int8 MFMA) of every frame against the previous one",
             "c5": "dense 2-NN Hamming match (int8 MFMA) of every frame against the previous one",
             "c4": "%d fisheye stereo pairs: brute-force 2-NN of left x right descriptors per pair + Lowe ratio 0.7 in the kernel's epilogue (ComputeStereoFishEyeMatches, Frame.cc:1458-1465)" % (B // 2),
-            "c3": "%d stereo pairs (the stereo Frame constructor, Frame.cc:103-200, + what LocalMapping does with a new KeyFrame): ComputeStereoMatches and AssignFeaturesToGrid per pair, ComputeBoW buckets (synthetic k=10 L=3 vocabulary) and one SearchForTriangulation_ per pair "
+            "c3": "%d stereo pairs (the stereo Frame constructor, Frame.cc:103-200, + what LocalMapping does with a new KeyFrame): ComputeStereoMatches and AssignFeaturesToGrid per pair, ComputeBoW buckets (seeded vocabulary of ORBvoc's shape: k=10, L=6, levelsup=4) and one SearchForTriangulation_ per pair "
                   "(its left image against the right image of the previous step as the neighbouring KeyFrame)" % (B // 2)}
     if args.match == "window":
         legs["c2"] = legs["c5"] = ("AssignFeaturesToGrid + SearchByProjection(frame, previous frame, th=15, mono; ORBmatcher.cc:2469-2711) of every frame, "

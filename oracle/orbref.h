@@ -170,6 +170,7 @@ int orbref_search_by_sim3(const orbref_frame_t* kf1, const orbref_frame_t* kf2, 
  * the leaves and the word weight (0 = stopped).  Returns 0 or -1 (bad file). */
 typedef struct orbref_vocab orbref_vocab_t;
 orbref_vocab_t* orbref_vocab_load_text(const char* path);
+orbref_vocab_t* orbref_vocab_create(int k, int L, int nnodes, const int32_t* parent, const uint8_t* is_leaf, const uint8_t* desc, const double* weight);
 void orbref_vocab_destroy(orbref_vocab_t*);
 int orbref_vocab_info(const orbref_vocab_t*, int* k, int* L, int* nnodes, int* nwords);
 int orbref_bow_transform(const orbref_vocab_t*, const uint8_t* desc, int n, int levelsup,

@@ -275,7 +275,16 @@ class Vocabulary:
         L.orbref_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orbref_bow_vectors.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int),
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.orbref_vocab_create.restype = C.c_void_p
+        L.orbref_vocab_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         self.L = L
+        if isinstance(path, dict):                                  # arrays: k, L, parent, is_leaf, desc, weight (orbref_vocab_create)
+            a = path
+            keep = [np.ascontiguousarray(a["parent"], np.int32), np.ascontiguousarray(a["is_leaf"], np.uint8),
+                    np.ascontiguousarray(a["desc"], np.uint8), np.ascontiguousarray(a["weight"], np.float64)]
+            self.h = L.orbref_vocab_create(int(a["k"]), int(a["L"]), len(keep[0]), *[_p(x) for x in keep])
+            assert self.h, "oracle could not build the tree"
+            return
         self.h = L.orbref_vocab_load_text(path.encode())
         assert self.h, "oracle could not load " + path
 

@@ -53,6 +53,24 @@ orbref_vocab_t* orbref_vocab_load_text(const char* path) {
     }
     return v;
 }
+// The same tree from arrays (node 0 = root; parent[i] < i): what loadFromTextFile builds line by line (:1385-1420) -- children in
+// node-id order, word ids in leaf order -- without a 150 MB text file for an ORBvoc-sized tree (k = 10, L = 6: 1 111 111 nodes).
+orbref_vocab_t* orbref_vocab_create(int k, int L, int nnodes, const int32_t* parent, const uint8_t* is_leaf, const uint8_t* desc, const double* weight) {
+    if (nnodes < 2) return nullptr;
+    orbref_vocab* v = new orbref_vocab;
+    v->k = k; v->L = L;
+    v->nodes.resize(nnodes);
+    for (int nid = 1; nid < nnodes; ++nid) {
+        VNode& nd = v->nodes[nid];
+        nd.id = nid; nd.parent = parent[nid];
+        if (nd.parent < 0 || nd.parent >= nid) { delete v; return nullptr; }
+        v->nodes[nd.parent].children.push_back(nid);
+        memcpy(nd.d, desc + 32 * (size_t)nid, 32);
+        nd.weight = weight[nid];
+        if (is_leaf[nid]) { nd.word_id = (int)v->words.size(); v->words.push_back(nid); }
+    }
+    return v;
+}
 void orbref_vocab_destroy(orbref_vocab_t* v) { delete v; }
 int orbref_vocab_info(const orbref_vocab_t* v, int* k, int* L, int* nnodes, int* nwords) {
     *k = v->k; *L = v->L; *nnodes = (int)v->nodes.size(); *nwords = (int)v->words.size(); return 0;

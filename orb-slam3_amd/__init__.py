@@ -918,7 +918,13 @@ class ORBVocabulary:
     def __init__(self, matcher, path):
         self.L = lib(); self.m = matcher
         h = C.c_void_p()
-        _chk(self.L.orbm_vocab_load_text(matcher.h, C.byref(h), path.encode()), "orbm_vocab_load_text")
+        if isinstance(path, dict):                                  # arrays: k, L, parent, is_leaf, desc, weight (orbm_vocab_create)
+            a = path
+            arr = [np.ascontiguousarray(a["parent"], np.int32), np.ascontiguousarray(a["is_leaf"], np.uint8),
+                   np.ascontiguousarray(a["desc"], np.uint8), np.ascontiguousarray(a["weight"], np.float64)]
+            _chk(self.L.orbm_vocab_create(matcher.h, C.byref(h), int(a["k"]), int(a["L"]), len(arr[0]), *[_p(x) for x in arr]), "orbm_vocab_create")
+        else:
+            _chk(self.L.orbm_vocab_load_text(matcher.h, C.byref(h), path.encode()), "orbm_vocab_load_text")
         self.h = h
 
     def info(self):

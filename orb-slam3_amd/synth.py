@@ -95,3 +95,24 @@ def gen_stereo_pair(w, h, seed, dmin=2, dmax=40):
     right = left[rows, x0] * (1 - f) + left[rows, x1] * f
     right += rng.normal(0, 2.0, right.shape)
     return left, np.clip(np.rint(right), 0, 255).astype(np.uint8)
+
+
+def gen_vocabulary(k=10, L=6, seed=7, tie_every=997):
+    """A seeded complete k-ary vocabulary tree of depth L as arrays (ORBvoc.txt -- k = 10, L = 6, Frame.cc:905-918 uses it with
+    levelsup = 4 -- is a missing blob in the reference snapshot): node 0 = root, breadth-first ids (siblings consecutive, as DBoW2's
+    HKmeansStep numbers them), random 256-bit node descriptors, idf-like weights, a few stopped words (weight 0).  Every `tie_every`-th
+    inner node gets two children with the SAME descriptor: the descent must take the earlier one (strict `d < best_d`,
+    TemplatedVocabulary.h:1239-1250).  Returns the dict the vocabulary classes take."""
+    rng = np.random.default_rng(seed)
+    nnodes = (k ** (L + 1) - 1) // (k - 1)
+    parent = np.zeros(nnodes, np.int32)
+    ids = np.arange(1, nnodes, dtype=np.int64)
+    parent[1:] = (ids - 1) // k
+    first_leaf = (k ** L - 1) // (k - 1)
+    is_leaf = np.zeros(nnodes, np.uint8); is_leaf[first_leaf:] = 1
+    desc = rng.integers(0, 256, (nnodes, 32), dtype=np.uint8)
+    inner = np.arange(0, first_leaf, tie_every)
+    desc[inner * k + 4] = desc[inner * k + 2]                  # children 2 and 4 (1-based ids k*p + 1 ..): equal distance to everything
+    weight = rng.uniform(0.1, 9.0, nnodes)
+    weight[first_leaf + rng.integers(0, nnodes - first_leaf, max(1, (nnodes - first_leaf) // 200))] = 0.0
+    return dict(k=k, L=L, parent=parent, is_leaf=is_leaf, desc=desc, weight=weight)

@@ -70,3 +70,32 @@ def test_vocab_errors(pkg, tmp_path):
     bad = tmp_path / "bad.txt"; bad.write_text("99 3 0 0\n")
     with pytest.raises(pkg.OrbError):
         pkg.ORBVocabulary(m, str(bad))
+
+
+def test_bow_transform_at_orbvoc_scale(pkg, oracle, synth):
+    """8(f).1 at the size of the stock vocabulary: k = 10, L = 6 (1 111 111 nodes, 35.6 MB of node descriptors -- more than the
+    32 MB of aggregate L2), levelsup = 4 as Frame::ComputeBoW calls it (Frame.cc:905-918).  Word id, node id and weight of every
+    feature of two 1200-feature frames + random rows equal the oracle's; ties between two children resolve to the earlier child."""
+    tree = synth.gen_vocabulary(10, 6, seed=7)
+    m = pkg.ORBmatcher(0.7)
+    voc = pkg.ORBVocabulary(m, tree); ref = oracle.Vocabulary(tree)
+    assert voc.info() == ref.info() == dict(k=10, L=6, nnodes=1111111, nwords=1000000)
+    ex = pkg.ORBextractor(1200, max_size=(752, 480))
+    l, r = synth.gen_stereo_pair(752, 480, 77)
+    _, _, dl = ex(l, (0, 0)); _, _, dr = ex(r, (0, 0))
+    rng = np.random.default_rng(3)
+    # rows that are EXACT copies of tied node descriptors walk into the tie at distance 0
+    tied = tree["desc"][np.arange(0, 111111, 997) * 10 + 2][:64]
+    desc = np.concatenate([dl, dr, rng.integers(0, 256, (500, 32), dtype=np.uint8), tied])
+    (bi, bv), (fn, fs, fi), w, nd, wt = voc.transform(desc, 4)
+    (rbi, rbv), (rfn, rfs, rfi), rw, rnd, rwt = ref.transform(desc, 4)
+    assert np.array_equal(w, rw) and np.array_equal(nd, rnd) and wt.tobytes() == rwt.tobytes()
+    assert np.array_equal(bi, rbi) and bv.tobytes() == rbv.tobytes()
+    assert np.array_equal(fn, rfn) and np.array_equal(fs, rfs) and np.array_equal(fi, rfi)
+    assert nd.min() >= 11 and nd.max() <= 110                           # levelsup = 4 of L = 6: the 100 nodes of tree level 2
+    # the batched device form (ComputeBoW buckets of whole result blocks) agrees
+    dd = pkg.DeviceBuffer(desc.nbytes); dd.upload(desc)
+    dn = pkg.DeviceBuffer(4 * len(desc))
+    assert m.L.orbm_bow_nodes_batch_async(m.h, voc.h, dd.ptr, len(desc), 4, dn.ptr) == 0
+    m.sync()
+    assert np.array_equal(dn.download(np.int32, len(desc)), rnd)
