@@ -400,3 +400,34 @@ def test_pyramid_map_views(pkg, synth):
     for lv in range(1, 8):
         assert np.array_equal(np.array(views[lv]), ex.level_image(lv)), lv
     ex.close()
+
+
+def test_pyramid_level0_after_a_misaligned_device_batch(pkg, synth):
+    """A host-image call leaves its frame in the pinned staging buffer; a later DEVICE batch with a misaligned stride is staged
+    device-to-device into the same level-0 area.  The host views / fetches of level 0 must then show the DEVICE batch's image,
+    not the older host image still sitting in the staging buffer (round-2 advisor finding)."""
+    import ctypes as C
+    w, h = 641, 479
+    a = synth.gen_image(w, h, 51); b = synth.gen_image(w, h, 52)
+    assert not np.array_equal(a, b)
+    ex = pkg.ORBextractor(500, max_size=(w, h), max_batch=1)
+    ex(a, (0, 0))                                                          # host path: staged through hPinned
+    assert np.array_equal(ex.pyramid_views(0)[0], a)
+    stride = w + 3                                                         # neither the stride nor the pointer is 16-byte aligned
+    dev = pkg.DeviceBuffer(stride * h + 64)
+    padded = np.zeros((h, stride), np.uint8); padded[:, :w] = b
+    dev.upload(padded, offset=5)
+    ptrs = (C.c_void_p * 1)(int(dev.ptr + 5))
+    ex.enqueue_device(ptrs, w, h, stride, [(0, 0)])
+    ex.sync()
+    views = ex.pyramid_views(0)
+    # (level 0 of a device batch has no host copy: the map reports none -- what it must never report is the older host frame)
+    assert views[0] is None or np.array_equal(np.array(views[0]), b), "level 0 of the device batch came back as the older host image"
+    assert np.array_equal(ex.level_image(0), b)
+    fetched = ex.pyramid_fetch(0)
+    assert np.array_equal(fetched[0], b), "orbx_pyramid_fetch returned the stale staging copy for level 0"
+    for lv in range(1, 8):
+        assert np.array_equal(np.array(views[lv]), ex.level_image(lv)), lv
+    ex(a, (0, 0))                                                          # and back: the host path is zero-copy again
+    assert np.array_equal(ex.pyramid_views(0)[0], a)
+    ex.close()

@@ -482,6 +482,35 @@ def test_resident_frame_search_by_projection_frame(pkg, scene, th, fwd, bwd, ste
     res.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_resident_frame_searches_on_tie_heavy_descriptors(pkg, scene, seed):
+    """The resident searches return the 8 best candidates per window in (distance, VISITING ORDER) rank; the replay relies on that
+    order whenever distances tie.  Here the searched frame's descriptors are drawn from only 12 distinct rows (and the queries from
+    the same 12), so that nearly every window holds several candidates at the same distance -- often more than eight: M4 and M3 on
+    the resident frame must still equal the oracle entry for entry, over several seeds."""
+    rng = np.random.default_rng(1000 + seed)
+    kr = scene["kr"]; n_t = len(kr)
+    pool = rng.integers(0, 256, (12, 32), dtype=np.uint8)
+    dt = pool[rng.integers(0, 12, n_t)]
+    n, u, v = _queries(scene, rng, jitter=4.0)
+    dq = pool[rng.integers(0, 12, n)]
+    view = pkg.FrameView(kr, dt, 752, 480, backend=scene["OM"])
+    res = pkg.ResidentFrame(scene["m"], view)
+    args = dict(cur_blocked=rng.random(n_t) < 0.3, scale_factors=scene["sf"], valid=rng.random(n) < 0.9, u=u, v=v,
+                invzc=rng.uniform(0.05, 1.0, n), octave=scene["kl"]["octave"], angle=scene["kl"]["angle"], qdesc=dq,
+                mp_obs=rng.random(n) < 0.8, th=30, forward=False, backward=False, mbf=47.9, check_ori=True)
+    n_gpu, m_gpu = scene["m"].SearchByProjectionFrameResident(res, **args)
+    n_ref, m_ref = scene["OM"].SearchByProjectionFrame(view, **args)
+    assert n_gpu == n_ref and np.array_equal(m_gpu, m_ref) and n_ref > 30, (n_gpu, n_ref, np.flatnonzero(m_gpu != m_ref)[:8])
+    args3 = dict(blocked=rng.random(n_t) < 0.3, scale_factors=scene["sf"], in_view=rng.random(n) < 0.9, px=u, py=v,
+                 pxr=(u - rng.uniform(2, 40, n)).astype(np.float32), view_cos=rng.uniform(0.99, 1.0, n),
+                 level=scene["kl"]["octave"], qdesc=dq, mp_obs=rng.random(n) < 0.8, th=8.0, nnratio=0.9)
+    n_gpu, m_gpu = scene["m"].SearchByProjectionPointsResident(res, **args3)
+    n_ref, m_ref = scene["OM"].SearchByProjectionPoints(view, **args3)
+    assert n_gpu == n_ref and np.array_equal(m_gpu, m_ref)
+    res.close()
+
+
 @pytest.mark.parametrize("th,nnratio,stereo,pblock", [(1.0, 0.8, False, 0.05), (3.0, 0.8, True, 0.05), (5.0, 0.9, False, 0.9), (8.0, 0.9, True, 0.5)])
 def test_resident_frame_search_by_projection_points(pkg, scene, th, nnratio, stereo, pblock):
     rng = np.random.default_rng(int(th * 10) + 1)
