@@ -424,7 +424,7 @@ def test_pyramid_level0_after_a_misaligned_device_batch(pkg, synth):
     # (level 0 of a device batch has no host copy: the map reports none -- what it must never report is the older host frame)
     assert views[0] is None or np.array_equal(np.array(views[0]), b), "level 0 of the device batch came back as the older host image"
     assert np.array_equal(ex.level_image(0), b)
-    fetched = ex.pyramid_fetch(0)
+    fetched = ex.pyramid(0)
     assert np.array_equal(fetched[0], b), "orbx_pyramid_fetch returned the stale staging copy for level 0"
     for lv in range(1, 8):
         assert np.array_equal(np.array(views[lv]), ex.level_image(lv)), lv
