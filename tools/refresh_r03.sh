@@ -1,0 +1,20 @@
+#!/bin/bash
+# Regenerates the round-3 figures under gpurun_out/refresh3/ (copy into profiles/ afterwards): bench lines, kernel stats, PMC passes.
+set -o pipefail
+out=$GRAFT_REPO_ROOT/gpurun_out/refresh3; mkdir -p $out
+if [ "$1" = bench ]; then
+  python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r03_bench_c2.json 2> $out/bench_c2.err; tail -c 200 $out/r03_bench_c2.json; echo
+  python bench.py --steps 20 --warmup 5 --match window > $out/r03_bench_c2_window.json 2> $out/bench_c2w.err; tail -c 200 $out/r03_bench_c2_window.json; echo
+  for c in c3 c4 c5; do python bench.py --config $c --steps 20 --warmup 5 > $out/r03_bench_$c.json 2> $out/bench_$c.err; tail -c 200 $out/r03_bench_$c.json; echo; done
+  python bench.py --config c4 --batch 512 --steps 20 --warmup 5 > $out/r03_bench_c4_b512.json 2> $out/bench_c4b.err; tail -c 200 $out/r03_bench_c4_b512.json; echo
+  python tools/latency_breakdown.py > $out/r03_latency.txt 2>&1; tail -5 $out/r03_latency.txt
+else
+  for c in c2 c3 c4 c5; do bash tools/prof.sh refresh3/prof_$c --config $c > $out/prof_$c.txt 2>&1; cp $GRAFT_REPO_ROOT/gpurun_out/refresh3/prof_${c}_kernel_stats.csv $out/r03_kernel_stats_$c.csv 2>/dev/null; echo prof $c done; done
+  bash tools/prof.sh refresh3/prof_c2w --match window > $out/prof_c2w.txt 2>&1; cp $GRAFT_REPO_ROOT/gpurun_out/refresh3/prof_c2w_kernel_stats.csv $out/r03_kernel_stats_c2_window.csv 2>/dev/null; echo prof c2 window done
+  bash tools/prof.sh refresh3/prof_c2s --texture sparse --distinct 48 > $out/prof_c2s.txt 2>&1; cp $GRAFT_REPO_ROOT/gpurun_out/refresh3/prof_c2s_kernel_stats.csv $out/r03_kernel_stats_c2_sparse.csv 2>/dev/null; echo prof c2 sparse done
+  PMC_BENCH_ARGS="--config c5 --batch 16" bash tools/pmc.sh refresh3/pmc_fetch_c5 FETCH_SIZE > $out/pmc_fetch_c5.txt 2>&1 && echo fetch c5 done
+  PMC_BENCH_ARGS="--config c5 --batch 16" bash tools/pmc.sh refresh3/pmc_write_c5 WRITE_SIZE > $out/pmc_write_c5.txt 2>&1 && echo write c5 done
+  PMC_BENCH_ARGS="--config c5 --batch 16" bash tools/pmc.sh refresh3/pmc_sq_c5 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU > $out/r03_pmc_sq_per_launch_c5.txt 2>&1 && echo sq c5 done
+  python tools/make_traffic_json.py gpurun_out/refresh3/pmc_fetch_c5 gpurun_out/refresh3/pmc_write_c5 1920 1080 4000 16 c5 17023027 12838642 && cp profiles/r03_traffic_c5.json profiles/r03_pmc_*_c5_counter_collection.csv $out/
+  python tools/make_valu_json.py gpurun_out/refresh3/pmc_sq_c5 1920 1080 4000 16 c5 && cp profiles/r03_valu_c5.json $out/
+fi
