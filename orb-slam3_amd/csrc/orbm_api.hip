@@ -1172,7 +1172,9 @@ int orbm_search_by_projection_batch_async(orbm_t* m, const orbm_kp_t* kps, const
 // ---- DBoW2 vocabulary ----
 struct orbm_vocab {
     int k = 0, L = 0, nnodes = 0, nwords = 0, device = 0;
-    int *dChildStart = nullptr, *dChildIdx = nullptr, *dWord = nullptr;
+    // level-major layout (k_bow_transform2): node rows renumbered breadth-first, the children of a node contiguous in child order
+    unsigned* dInfo = nullptr;                                 // [nnodes] first child << 5 | child count
+    int *dOrig = nullptr, *dWord = nullptr;                    // [nnodes] the vocabulary's own node id; word id (leaves)
     uint8_t* dDesc = nullptr;
     double* dWeight = nullptr;
 };
@@ -1180,8 +1182,8 @@ struct orbm_vocab {
 void orbm_vocab_destroy(orbm_vocab_t* v) {
     if (!v) return;
     (void)hipSetDevice(v->device);
-    void* ps[] = {v->dChildStart, v->dChildIdx, v->dWord, v->dDesc, v->dWeight};
-    for (void* p : ps) if (p) (void)hipFree(p);
+    void* ptrs[] = {v->dInfo, v->dOrig, v->dWord, v->dDesc, v->dWeight};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
     delete v;
 }
 
@@ -1199,19 +1201,42 @@ int orbm_vocab_create(orbm_t* m, orbm_vocab_t** out, int k, int L, int nnodes, c
     std::vector<int> fill(cstart.begin(), cstart.end() - 1);
     int nwords = 0;
     for (int i = 1; i < nnodes; ++i) { cidx[fill[parent[i]]++] = i; if (is_leaf[i]) word[i] = nwords++; }
-    for (int i = 1; i < nnodes; ++i)
+    for (int i = 1; i < nnodes; ++i) {
         if ((cstart[i + 1] == cstart[i]) != (is_leaf[i] != 0)) { set_merr("vocabulary node %d: leaf flag disagrees with its children", i); return ORBM_E_INVALID; }
+        if (cstart[i + 1] - cstart[i] > 31) { set_merr("vocabulary node %d has %d children (at most 31 supported; DBoW2 allows k <= 20)", i, cstart[i + 1] - cstart[i]); return ORBM_E_INVALID; }
+    }
+    if (cstart[1] - cstart[0] > 31) { set_merr("vocabulary root has more than 31 children"); return ORBM_E_INVALID; }
+    // level-major renumbering: breadth-first from the root, children of a node consecutive in their child-list order
+    std::vector<int> order; order.reserve(nnodes);             // new row -> vocabulary node id
+    std::vector<int> newOf(nnodes, -1);
+    order.push_back(0); newOf[0] = 0;
+    for (size_t h = 0; h < order.size(); ++h) {
+        const int id = order[h];
+        for (int c = cstart[id]; c < cstart[id + 1]; ++c) { newOf[cidx[c]] = (int)order.size(); order.push_back(cidx[c]); }
+    }
+    if ((int)order.size() != nnodes) { set_merr("vocabulary is not one tree (%zu of %d nodes reachable from the root)", order.size(), nnodes); return ORBM_E_INVALID; }
+    std::vector<unsigned> info(nnodes);
+    std::vector<int> wordN(nnodes);
+    std::vector<double> weightN(nnodes);
+    std::vector<uint8_t> descN((size_t)32 * nnodes);
+    for (int r = 0; r < nnodes; ++r) {
+        const int id = order[r];
+        const int cnt = cstart[id + 1] - cstart[id];
+        info[r] = cnt ? ((unsigned)newOf[cidx[cstart[id]]] << 5) | (unsigned)cnt : 0u;
+        wordN[r] = word[id]; weightN[r] = weight[id];
+        memcpy(&descN[(size_t)32 * r], desc + (size_t)32 * id, 32);
+    }
     MHIPCHK(hipSetDevice(m->device));
     orbm_vocab* v = new orbm_vocab;
     v->k = k; v->L = L; v->nnodes = nnodes; v->nwords = nwords; v->device = m->device;
-    bool ok = hipMalloc((void**)&v->dChildStart, sizeof(int) * (nnodes + 1)) == hipSuccess && hipMalloc((void**)&v->dChildIdx, sizeof(int) * nnodes) == hipSuccess &&
+    bool ok = hipMalloc((void**)&v->dInfo, sizeof(unsigned) * nnodes) == hipSuccess && hipMalloc((void**)&v->dOrig, sizeof(int) * nnodes) == hipSuccess &&
               hipMalloc((void**)&v->dWord, sizeof(int) * nnodes) == hipSuccess && hipMalloc((void**)&v->dDesc, (size_t)32 * nnodes) == hipSuccess &&
               hipMalloc((void**)&v->dWeight, sizeof(double) * nnodes) == hipSuccess;
-    ok = ok && hipMemcpy(v->dChildStart, cstart.data(), sizeof(int) * (nnodes + 1), hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(v->dChildIdx, cidx.data(), sizeof(int) * (nnodes - 1), hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(v->dWord, word.data(), sizeof(int) * nnodes, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(v->dDesc, desc, (size_t)32 * nnodes, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(v->dWeight, weight, sizeof(double) * nnodes, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(v->dInfo, info.data(), sizeof(unsigned) * nnodes, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->dOrig, order.data(), sizeof(int) * nnodes, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->dWord, wordN.data(), sizeof(int) * nnodes, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->dDesc, descN.data(), (size_t)32 * nnodes, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->dWeight, weightN.data(), sizeof(double) * nnodes, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { set_merr("vocabulary upload failed"); orbm_vocab_destroy(v); return ORBM_E_HIP; }
     *out = v;
     return ORBM_OK;
@@ -1261,8 +1286,8 @@ int orbm_bow_transform(orbm_t* m, const orbm_vocab_t* v, const uint8_t* desc, in
     m->gridFirst = false;
     MHIPCHK(rec_time(m, m->e0));
     ARENA_FLUSH(m);
-    hipLaunchKernelGGL(k_bow_transform, dim3((n + 255) / 256), dim3(256), 0, m->stream, dd.as<uint8_t>(), n, v->dChildStart, v->dChildIdx,
-                       v->dDesc, v->dWord, v->dWeight, v->L, levelsup, dw.as<int>(), dn.as<int>(), dwt.as<double>());
+    hipLaunchKernelGGL(k_bow_transform2, dim3((unsigned)(((size_t)n * 16 + 255) / 256)), dim3(256), 0, m->stream, dd.as<uint8_t>(), n, v->dInfo,
+                       v->dDesc, v->dOrig, v->dWord, v->dWeight, v->L, levelsup, dw.as<int>(), dn.as<int>(), dwt.as<double>());
     MHIPCHK(rec_time(m, m->e1));
     m->timed = true;
     MHIPCHK(hipGetLastError());
@@ -1690,8 +1715,8 @@ int orbm_bow_nodes_batch_async(orbm_t* m, const orbm_vocab_t* v, const uint8_t* 
     if (!m || !v || !desc || !node_id || nrows < 1) return ORBM_E_INVALID;
     if (v->device != m->device) { set_merr("vocabulary lives on another device"); return ORBM_E_INVALID; }
     MHIPCHK(hipSetDevice(m->device));
-    hipLaunchKernelGGL(k_bow_transform, dim3((nrows + 255) / 256), dim3(256), 0, m->stream, desc, nrows, v->dChildStart, v->dChildIdx, v->dDesc, v->dWord, v->dWeight,
-                       v->L, levelsup, (int*)nullptr, node_id, (double*)nullptr);
+    hipLaunchKernelGGL(k_bow_transform2, dim3((unsigned)(((size_t)nrows * 16 + 255) / 256)), dim3(256), 0, m->stream, desc, nrows, v->dInfo, v->dDesc, v->dOrig,
+                       v->dWord, v->dWeight, v->L, levelsup, (int*)nullptr, node_id, (double*)nullptr);
     MHIPCHK(hipGetLastError());
     return ORBM_OK;
 }

@@ -1392,43 +1392,62 @@ __global__ __launch_bounds__(64) void k_track_claim(const KpIn* __restrict__ kps
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_bow_transform: DBoW2 TemplatedVocabulary::transform (TemplatedVocabulary.h:1196-1262) for a batch of
-// descriptors.  One thread per descriptor walks the k-ary tree: at every level the child with the smallest
-// Hamming distance (first minimum, strict <) is taken; the node reached at level L-levelsup is recorded.
-// Children of a node are contiguous (CSR), node descriptors are rows of one array.
+// k_bow_transform2: DBoW2 TemplatedVocabulary::transform (TemplatedVocabulary.h:1196-1262) for a batch of descriptors: at every level the
+// child with the smallest Hamming distance (first minimum, strict <) is taken; the node reached at level L - levelsup is recorded.
+// The tree is in the level-major layout the host builds (orbm_vocab_create): nodes renumbered breadth-first so
+// that the children of a node are CONTIGUOUS rows in its own child order; info[n] = first child << 5 | child count; orig[n] = the
+// vocabulary's node id.  16 lanes per descriptor (4 descriptors per wave): lane c takes child c, the 16-lane minimum of
+// (distance << 5 | c) by four DPP row rotations picks the first-minimum child (strict `d < best_d` in child order,
+// TemplatedVocabulary.h:1239-1250).  A wave instruction then touches the 3 lines of each of its 4 child blocks instead of 64 scattered
+// rows -- at ORBvoc's size (35.6 MB of node descriptors) the L1 line rate, not the arithmetic, bounds the thread-per-descriptor kernel.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bow_transform(const uint8_t* __restrict__ desc, int n, const int* __restrict__ child_start,
-                                                       const int* __restrict__ child_idx, const uint8_t* __restrict__ ndesc,
-                                                       const int* __restrict__ nword, const double* __restrict__ nweight,
-                                                       int L, int levelsup, int* __restrict__ word_id, int* __restrict__ node_id,
-                                                       double* __restrict__ weight) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint4* qp = (const uint4*)(desc + (size_t)i * 32);
+__device__ __forceinline__ unsigned row16_min_u32(unsigned v) {
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false));   // row_ror:8
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false));   // row_ror:4
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xf, 0xf, false));   // row_ror:2
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v;
+}
+__global__ __launch_bounds__(256) void k_bow_transform2(const uint8_t* __restrict__ desc, int n, const unsigned* __restrict__ info,
+                                                        const uint8_t* __restrict__ ndesc, const int* __restrict__ orig,
+                                                        const int* __restrict__ nword, const double* __restrict__ nweight,
+                                                        int L, int levelsup, int* __restrict__ word_id, int* __restrict__ node_id,
+                                                        double* __restrict__ weight) {
+    const int c = threadIdx.x & 15;
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 4;
+    const bool live = i < n;
+    const uint4* qp = (const uint4*)(desc + (size_t)(live ? i : 0) * 32);
     const uint4 qlo = qp[0], qhi = qp[1];
     const u64 a[4] = {(u64)qlo.x | ((u64)qlo.y << 32), (u64)qlo.z | ((u64)qlo.w << 32),
                       (u64)qhi.x | ((u64)qhi.y << 32), (u64)qhi.z | ((u64)qhi.w << 32)};
     const int nid_level = L - levelsup;
-    int nid = 0, final_id = 0, level = 0;
+    int cur = 0, nid = 0, level = 0;
     for (;;) {
-        const int c0 = child_start[final_id], c1 = child_start[final_id + 1];
-        if (c0 == c1) break;                                                    // leaf
+        const unsigned inf = info[cur];
+        const int cnt = (int)(inf & 31u), first = (int)(inf >> 5);
+        // (uniform inside a 16-lane group; groups of a wave may leave at different levels: the DPP rotations stay inside a row)
+        if (cnt == 0) break;
         ++level;
-        int best = 1 << 20, bid = 0;
-        for (int c = c0; c < c1; ++c) {
-            const int id = child_idx[c];
-            const uint4* tp = (const uint4*)(ndesc + (size_t)id * 32);
-            const uint4 lo = tp[0], hi = tp[1];
-            const int d = ham256(a, (u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
-                                 (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32));
-            if (d < best) { best = d; bid = id; }
+        unsigned best = 0xFFFFFFFFu;
+        for (int c0 = 0; c0 < cnt; c0 += 16) {                             // k <= 16 in one step (DBoW2 allows k up to 20)
+            unsigned key = 0xFFFFFFFFu;
+            if (c0 + c < cnt) {
+                const uint4* tp = (const uint4*)(ndesc + (size_t)(first + c0 + c) * 32);
+                const uint4 lo = tp[0], hi = tp[1];
+                const int d = ham256(a, (u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
+                                     (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32));
+                key = ((unsigned)d << 5) | (unsigned)(c0 + c);
+            }
+            best = min(best, row16_min_u32(key));
         }
-        final_id = bid;
-        if (level == nid_level) nid = final_id;
+        cur = first + (int)(best & 31u);
+        if (level == nid_level) nid = cur;
     }
-    if (word_id) word_id[i] = nword[final_id];
-    if (weight) weight[i] = nweight[final_id];
-    node_id[i] = nid;
+    if (live && c == 0) {
+        if (word_id) word_id[i] = nword[cur];
+        if (weight) weight[i] = nweight[cur];
+        node_id[i] = nid ? orig[nid] : 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
