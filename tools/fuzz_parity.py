@@ -24,7 +24,7 @@ for case in range(ncases):
         continue
     nf = int(rng.integers(100, 3000))
     ini = int(rng.integers(8, 40)); mn = int(rng.integers(2, ini + 1))
-    kind = str(rng.choice(["textured", "textured", "textured", "lowcontrast"]))
+    kind = str(rng.choice(["textured", "textured", "sparse", "lowcontrast"]))
     lap = (int(rng.integers(0, w)), int(rng.integers(0, w + 200)))
     img = synth.gen_image(w, h, int(rng.integers(1, 10**6)), kind)
     try:
