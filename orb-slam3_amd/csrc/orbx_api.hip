@@ -372,10 +372,10 @@ static int build_geometry(orbx* o, int w, int h) {
                     if (tb.s < 0 || tb.a0 < 0 || tb.a1 < 0) { ok = false; break; }
                     if (tb.s + 1 < S.w) {
                         sx[i] = tb.s;
-                        e.a[i] = (u32)(unsigned short)tb.a0 | ((u32)(unsigned short)tb.a1 << 16);
+                        e.a[i] = (u32)(unsigned short)(2 * tb.a0) | ((u32)(unsigned short)(2 * tb.a1) << 16);   // doubled taps (<= 4096): k_resize2 keeps (H >> 4) << 5
                     } else {                                           // clamped last column (a1 == 0): pair (w-2, w-1), weight on the second
                         sx[i] = tb.s - 1;
-                        e.a[i] = (u32)(unsigned short)tb.a0 << 16;
+                        e.a[i] = (u32)(unsigned short)(2 * tb.a0) << 16;
                     }
                 }
                 if (!ok) break;

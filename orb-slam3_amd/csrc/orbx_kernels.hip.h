@@ -71,6 +71,12 @@ __device__ __forceinline__ u32 mad24(u32 a, u32 b, u32 c) {      // a*b + c on 2
     return d;
 }
 
+__device__ __forceinline__ u32 mulhi24(u32 a_uniform, u32 b) {   // bits 47..32 of the product of two 24-bit operands (a: wave-uniform), one VALU instruction
+    u32 d;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(d) : "s"(a_uniform), "v"(b));
+    return d;
+}
+
 // Loads through an explicit global address space: pointers fetched from memory (the per-frame level-0 table)
 // are generic to the compiler, which would emit flat_load + conservative vmcnt(0)/lgkmcnt(0) waits.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, const u8* const* l0, int
 // ------------------------------------------------------------------------------------------------
 #define RZ_R 8
 #define RZ_SRC 12                                          // source rows one task may touch (host checks)
-struct RzX4 { int bs; u8 o[4]; u32 a[4]; };                // per destination dword: byte offset of the first tap, tap offsets from it (<= 6), (a0 | a1<<16)
+struct RzX4 { int bs; u8 o[4]; u32 a[4]; };                // per destination dword: byte offset of the first tap, tap offsets from it (<= 6), (2*a0 | 2*a1<<16): DOUBLED Q11 taps
 struct RzTask { short level, g0, y0, pad; };
 
 __global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, int l0pitch, u8* pyr,
@@ -219,17 +225,21 @@ __global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, in
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const us2 s2 = as_us2(__builtin_amdgcn_perm(d[j].y, d[j].x, sel[i]));      // (byte o, byte o+1) as a u16 pair
-                Hc[i] = (int)(__builtin_amdgcn_udot2(s2, as_us2(X.a[i]), 0u, false) >> 4);   // only (H >> 4) is ever used
+                // only (H >> 4) is ever used; it is kept as (H >> 4) << 5 -- the table's taps are doubled, so that is one AND -- for the
+                // 24-bit high multiply below
+                Hc[i] = (int)(__builtin_amdgcn_udot2(s2, as_us2(X.a[i]), 0u, false) & ~31u);
             }
             if (dy < yend) {
                 const RzTab ty = yt[D.rzy + dy];
                 if (ty.s + 1 == sFirst + j) {                       // rows (sy, sy+1) = (j-1, j) are both here: emit dy
                     u32 packed = 0;
+                    // (b * (H >> 4)) >> 16 as ONE v_mul_hi_u32_u24: (b << 11) * ((H >> 4) << 5) = b * (H >> 4) * 2^16, whose bits 47..32 are
+                    // the wanted quotient (b <= 2048 -> 22 bits, (H >> 4) << 5 < 2^20: both operands fit 24 bits, nothing is rounded)
+                    const u32 A0 = (u32)ty.a0 << 11, A1 = (u32)ty.a1 << 11;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        // taps <= 2048 and H >> 4 < 2^15: 24-bit multiplies (v_mul_lo_u32 is quarter rate)
                         // each term is <= 1020, so (sum + 2) >> 2 <= 255: cv::resize's saturate_cast is the identity here
-                        const u32 v = (((u32)__mul24(ty.a0, Hp[i]) >> 16) + ((u32)__mul24(ty.a1, Hc[i]) >> 16) + 2u) >> 2;
+                        const u32 v = (mulhi24(A0, (u32)Hp[i]) + mulhi24(A1, (u32)Hc[i]) + 2u) >> 2;
                         packed |= v << (8 * i);
                     }
                     if (act) gstore32u(dst, (u32)(dy * D.pitch) + (u32)gcol * 4u, packed);
