@@ -2354,18 +2354,29 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
     const float a = (float)cd, b = (float)sd;
     // ---- descriptor: 16 pairs per lane, sampled from the LDS copy of the keypoint's 37-row blurred patch (the patch
     // rows were requested together with the orientation rows: one global round trip per wave instead of two)
-    const u8* pc = bpatch + ((threadIdx.x >> 6) * 4 + sub) * OD_PATCH_T + 18 * ppitch + bxoff;
+    // Rotation and rounding on PACKED f32 (v_pk_mul_f32 / v_pk_add_f32, two floats per instruction at full rate) -- same products, same
+    // sums, same rounding as the reference's scalar expressions (ORBextractor.cc:163-170):
+    //   (x*b, x*a) + (y*a, y*(-b)) = (x*b + y*a, x*a - y*b)        [(-b)*y == -(y*b) and p + (-q) == p - q exactly]
+    //   cvRound = rint: adding 1.5 * 2^23 leaves rint(v) in the mantissa for |v| < 2^22 (round-to-nearest-even, like v_rndne);
+    // the biased integers go straight into the address: mul_i24 sees 0x400000 + row (its low 24 bits), the column carries 0x4B400000,
+    // and the constant part is folded into the patch base.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 ba = {b, a}, anb = {a, -b}, magic = {12582912.0f, 12582912.0f};
+    const u32 pcA = (u32)(uintptr_t)(lds_u8_t*)(bpatch + ((threadIdx.x >> 6) * 4 + sub) * OD_PATCH_T + 18 * ppitch + bxoff)
+                    - (0x400000u * (u32)ppitch + 0x4B400000u);
     u8 t0[16], t1[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const u32 raw = spat[q * 16 + sl];
-        float4 pt;
-        pt.x = (float)(int)(int8_t)(raw & 0xFF); pt.y = (float)(int)(int8_t)((raw >> 8) & 0xFF);
-        pt.z = (float)(int)(int8_t)((raw >> 16) & 0xFF); pt.w = (float)((int)raw >> 24);
-        const int o0 = __mul24(__float2int_rn(pt.x * b + pt.y * a), ppitch) + __float2int_rn(pt.x * a - pt.y * b);   // 24-bit multiplies: full rate
-        const int o1 = __mul24(__float2int_rn(pt.z * b + pt.w * a), ppitch) + __float2int_rn(pt.z * a - pt.w * b);
-        t0[q] = valid ? pc[o0] : (u8)0;
-        t1[q] = valid ? pc[o1] : (u8)0;
+        const float x0 = (float)(int)(int8_t)(raw & 0xFF), y0 = (float)(int)(int8_t)((raw >> 8) & 0xFF);
+        const float x1 = (float)(int)(int8_t)((raw >> 16) & 0xFF), y1 = (float)((int)raw >> 24);
+        const f2 r0 = (f2{x0, x0} * ba + f2{y0, y0} * anb) + magic;        // (row, column) of the first sample, biased
+        const f2 r1 = (f2{x1, x1} * ba + f2{y1, y1} * anb) + magic;
+        const float r0r = r0.x, r0c = r0.y, r1r = r1.x, r1c = r1.y;      // (plain floats first: bit-casting a vector element reads element 0)
+        const u32 o0 = (u32)__mul24((int)__float_as_uint(r0r), ppitch) + __float_as_uint(r0c) + pcA;   // 24-bit multiply: full rate
+        const u32 o1 = (u32)__mul24((int)__float_as_uint(r1r), ppitch) + __float_as_uint(r1c) + pcA;
+        t0[q] = (u8)lds_r8(o0);                                      // (groups without a keypoint sample their own, unwritten patch slot: in bounds, never stored)
+        t1[q] = (u8)lds_r8(o1);
     }
     u32 myword = 0;
 #pragma unroll
