@@ -1158,8 +1158,12 @@ int orbm_search_by_projection_batch_async(orbm_t* m, const orbm_kp_t* kps, const
     const float factor = ORBM_HISTO_LENGTH / 360.0f;                        // ORBmatcher.cc:2478
     const size_t lds = (size_t)(((cap + 31) >> 5) + 32) * sizeof(unsigned);
     MHIPCHK(rec_time(m, m->e0));
-    hipLaunchKernelGGL(k_track_topk, dim3((cap + 3) / 4, npairs), dim3(256), 0, m->stream, (const KpIn*)kps, desc, counts, cap,
-                       grid_start, grid_idx, min_x, min_y, inv_w, inv_h, q_first, t_first, th, st, dx, dy, factor, topCnt, topKeys);
+    if (ab_env("ORBM_TOPK_WAVE"))                                           // A/B: a wave per query
+        hipLaunchKernelGGL(k_track_topk, dim3((cap + 3) / 4, npairs), dim3(256), 0, m->stream, (const KpIn*)kps, desc, counts, cap,
+                           grid_start, grid_idx, min_x, min_y, inv_w, inv_h, q_first, t_first, th, st, dx, dy, factor, topCnt, topKeys);
+    else
+        hipLaunchKernelGGL(k_track_topk16, dim3((cap + 15) / 16, npairs), dim3(256), 0, m->stream, (const KpIn*)kps, desc, counts, cap,
+                           grid_start, grid_idx, min_x, min_y, inv_w, inv_h, q_first, t_first, th, st, dx, dy, factor, topCnt, topKeys);
     hipLaunchKernelGGL(k_track_claim, dim3(npairs), dim3(64), lds, m->stream, (const KpIn*)kps, desc, counts, cap,
                        grid_start, grid_idx, min_x, min_y, inv_w, inv_h, q_first, t_first, th, st, dx, dy, factor, topCnt, topKeys,
                        t_blocked, q_obs, check_orientation, acc, match, nmatches);

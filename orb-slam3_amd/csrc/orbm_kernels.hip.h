@@ -1113,6 +1113,14 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+// minimum over the 16 lanes of a DPP row, in every lane of the row (four rotations)
+__device__ __forceinline__ unsigned row16_min_u32(unsigned v) {
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false));   // row_ror:8
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false));   // row_ror:4
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xf, 0xf, false));   // row_ror:2
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v;
+}
 __device__ __forceinline__ int wave_excl_scan(int v, int* total) {           // exclusive prefix sum over the 64 lanes
     int s = v;
     s += __builtin_amdgcn_update_dpp(0, s, 0x111, 0xf, 0xf, true);
@@ -1244,6 +1252,179 @@ __global__ __launch_bounds__(256) void k_track_topk(const KpIn* __restrict__ kps
     }
 }
 
+// k_track_topk16: the same lists with SIXTEEN lanes per query (four queries per wave).  A mono window (th = 15) holds 6 grid entries at
+// level 0 and ~40 at level 7 (14 on average over a 1000-feature frame), so a wave per query keeps most lanes idle and the kernel is bound
+// by the number of waves it can keep in flight across five dependent round trips.  A lane owns entries t = base + 16 j + l (j < NJ <= 4:
+// up to 64 entries per query and pass); column ranges sit in LDS (row-local prefix sums by DPP row_shr); the eight best come from
+// row-wide minimum reductions (DPP row_ror) whose winner writes its own word to the LDS list -- or, with one entry per lane, from
+// each lane counting the smaller keys of its row -- and later passes (windows of more than 64 grid entries) feed the list back in as
+// one more key per lane.  The pass body is BRANCH-FREE per NJ (inactive entries read row 0 instead of being predicated off), so that
+// the NJ loads of every step are in flight together; consecutive queries sit on the same pyramid level (similar windows), so NJ is
+// chosen per wave.
+struct Tk16 {
+    const int* gi; const KpIn* kt; const uint8_t* dt; int cap;
+    float x, y, r, qangle, factor; int minLevel, maxLevel;
+    int total, ncols, qr, l16, wr;
+};
+template <int NJ, bool FB>
+__device__ __forceinline__ void tk16_pass(const Tk16& c, const u64 (&a)[4], int base, int& cnt, const int2 (*sCol)[64], uint2 (*sTop)[TK_K]) {
+    const unsigned INV = 0xFFFFFFFFu;
+    int t[NJ], off[NJ], j0[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { t[j] = base + 16 * j + c.l16; off[j] = 0; j0[j] = 0; }
+    // each entry's column: the last one whose offset is <= t (columns ascending, empty ones share an offset)
+    for (int col = 0; __any(col < c.ncols); ++col) {
+        const int2 e = sCol[c.qr][col];
+        const bool in = col < c.ncols;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) if (in && t[j] >= e.x) { off[j] = e.x; j0[j] = e.y; }
+    }
+    int k[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) k[j] = c.gi[t[j] < c.total ? j0[j] + (t[j] - off[j]) : 0];
+    float kx[NJ], ky[NJ], ang[NJ];
+    int oct[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        k[j] = (int)min((unsigned)k[j], (unsigned)(c.cap - 1));              // (an unused entry's read of list slot 0 may hold anything)
+        const KpIn* kp = c.kt + k[j];
+        kx[j] = kp->x; ky[j] = kp->y; ang[j] = kp->angle; oct[j] = kp->octave;
+    }
+    bool ok[NJ];
+    uint4 lo[NJ], hi[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        ok[j] = t[j] < c.total && !(oct[j] < c.minLevel) && !(oct[j] > c.maxLevel) && (fabsf(kx[j] - c.x) < c.r && fabsf(ky[j] - c.y) < c.r);   // bCheckLevels is true here
+        const uint4* tp = (const uint4*)(c.dt + (size_t)(ok[j] ? k[j] : 0) * 32);
+        lo[j] = tp[0]; hi[j] = tp[1];
+    }
+    const unsigned below = (1u << c.l16) - 1u;
+    unsigned key[NJ + 1], word[NJ + 1];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const unsigned rowbits = (unsigned)(__ballot(ok[j]) >> (16 * c.wr)) & 0xFFFFu;
+        const int pos = cnt + __popc(rowbits & below);
+        const int d = ham256(a, (u64)lo[j].x | ((u64)lo[j].y << 32), (u64)lo[j].z | ((u64)lo[j].w << 32),
+                             (u64)hi[j].x | ((u64)hi[j].y << 32), (u64)hi[j].z | ((u64)hi[j].w << 32));
+        float rot = c.qangle - ang[j];
+        if (rot < 0.0f) rot += 360.0f;
+        int bin = (int)roundf(rot * c.factor);
+        if (bin == 30) bin = 0;
+        if (bin < 0 || bin >= 30) bin = TK_NOBIN;
+        key[j] = ok[j] ? ((unsigned)d << 16) | (unsigned)pos : INV;          // positions < 65536 (cap)
+        word[j] = ((unsigned)d << 21) | ((unsigned)bin << 16) | (unsigned)k[j];
+        cnt += __popc(rowbits);
+    }
+    key[NJ] = INV; word[NJ] = INV;
+    if (FB && c.l16 < TK_K) { const uint2 pv = sTop[c.qr][c.l16]; key[NJ] = pv.x; word[NJ] = pv.y; }   // the list so far competes again
+    if (NJ == 1 && !FB) {
+        // one key per lane: its rank = the number of smaller keys in the row (15 rotations; keys are unique by position)
+        int rank = 0;
+        unsigned rk = key[0];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+            rk = (unsigned)__builtin_amdgcn_update_dpp((int)rk, (int)rk, 0x121, 0xf, 0xf, false);   // row_ror:1
+            rank += rk < key[0] ? 1 : 0;
+        }
+        if (key[0] != INV && rank < TK_K) sTop[c.qr][rank] = make_uint2(key[0], word[0]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < TK_K; ++i) {
+            unsigned mine = key[0];
+#pragma unroll
+            for (int j = 1; j <= (FB ? NJ : NJ - 1); ++j) mine = min(mine, key[j]);
+            const unsigned m = row16_min_u32(mine);
+            if (!__any(m != INV)) break;
+            if (mine == m && m != INV) {                                    // keys are unique (position): exactly one lane of the row
+                unsigned w = word[0];
+#pragma unroll
+                for (int j = 1; j <= (FB ? NJ : NJ - 1); ++j) if (key[j] == m) w = word[j];
+                sTop[c.qr][i] = make_uint2(m, w);
+#pragma unroll
+                for (int j = 0; j <= (FB ? NJ : NJ - 1); ++j) if (key[j] == m) key[j] = INV;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256) void k_track_topk16(const KpIn* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                      const int* __restrict__ counts, int cap, const int* __restrict__ grid_start,
+                                                      const int* __restrict__ grid_idx, float min_x, float min_y, float inv_w, float inv_h,
+                                                      int q_first, int t_first, float th, ScaleTab st, float dx, float dy, float factor,
+                                                      int* __restrict__ out_cnt, unsigned int* __restrict__ out_keys) {
+    __shared__ int2 sCol[16][64];                                           // per query: (offset in the flattened list, first grid entry) of each window column
+    __shared__ uint2 sTop[16][TK_K];                                        // per query: (distance << 16 | position, output word), ascending
+    const int lane = threadIdx.x & 63, l16 = threadIdx.x & 15, wr = lane >> 4, qr = threadIdx.x >> 4;
+    const int pair = blockIdx.y;
+    const int qf = q_first + pair, tf = t_first + pair;
+    const int nq = min(counts[qf], cap);
+    if ((int)blockIdx.x * 16 >= nq) return;
+    const int q = blockIdx.x * 16 + qr;
+    const bool live = q < nq;
+    const KpIn kq = kps[(size_t)qf * cap + (live ? q : 0)];
+    const int* gs = grid_start + (size_t)tf * (64 * 48 + 1);
+    const float x = kq.x + dx, y = kq.y + dy, r = th * st.sf[kq.octave];
+    const unsigned INV = 0xFFFFFFFFu;
+    const int nMinCellX = max(0, (int)floorf((x - min_x - r) * inv_w));
+    const int nMaxCellX = min(63, (int)ceilf((x - min_x + r) * inv_w));
+    const int nMinCellY = max(0, (int)floorf((y - min_y - r) * inv_h));
+    const int nMaxCellY = min(47, (int)ceilf((y - min_y + r) * inv_h));
+    const bool hit = live && nMinCellX < 64 && nMaxCellX >= 0 && nMinCellY < 48 && nMaxCellY >= 0;
+    const int ncols = hit ? nMaxCellX - nMinCellX + 1 : 0;                  // <= 64
+    const uint4* qp = (const uint4*)(desc + ((size_t)qf * cap + (live ? q : 0)) * 32);
+    const uint4 qlo = qp[0], qhi = qp[1];
+    const u64 a[4] = {(u64)qlo.x | ((u64)qlo.y << 32), (u64)qlo.z | ((u64)qlo.w << 32),
+                      (u64)qhi.x | ((u64)qhi.y << 32), (u64)qhi.z | ((u64)qhi.w << 32)};
+    if (l16 < TK_K) sTop[qr][l16] = make_uint2(INV, INV);
+    int total = 0;
+    for (int cb = 0; __any(cb < ncols); cb += 16) {
+        const int c = cb + l16;
+        int cj0 = 0, clen = 0;
+        if (c < ncols) {
+            const int ix = nMinCellX + c;
+            cj0 = gs[ix * 48 + nMinCellY];
+            clen = gs[ix * 48 + nMaxCellY + 1] - cj0;
+        }
+        int sc = clen;                                                      // inclusive prefix sum inside the 16-lane row
+        sc += __builtin_amdgcn_update_dpp(0, sc, 0x111, 0xf, 0xf, true);
+        sc += __builtin_amdgcn_update_dpp(0, sc, 0x112, 0xf, 0xf, true);
+        sc += __builtin_amdgcn_update_dpp(0, sc, 0x114, 0xf, 0xf, true);
+        sc += __builtin_amdgcn_update_dpp(0, sc, 0x118, 0xf, 0xf, true);
+        if (c < ncols) sCol[qr][c] = make_int2(total + sc - clen, cj0);
+        const int s0 = __builtin_amdgcn_readlane(sc, 15), s1 = __builtin_amdgcn_readlane(sc, 31),
+                  s2 = __builtin_amdgcn_readlane(sc, 47), s3 = __builtin_amdgcn_readlane(sc, 63);
+        total += wr == 0 ? s0 : wr == 1 ? s1 : wr == 2 ? s2 : s3;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                  // a row lives inside one wave: LDS traffic of the same wave is ordered
+    __builtin_amdgcn_wave_barrier();
+    Tk16 c;
+    c.gi = grid_idx + (size_t)tf * cap; c.kt = kps + (size_t)tf * cap; c.dt = desc + (size_t)tf * cap * 32; c.cap = cap;
+    c.x = x; c.y = y; c.r = r; c.qangle = kq.angle; c.factor = factor; c.minLevel = kq.octave - 1; c.maxLevel = kq.octave + 1;
+    c.total = total; c.ncols = ncols; c.qr = qr; c.l16 = l16; c.wr = wr;
+    const int maxTotal = max(max(__builtin_amdgcn_readlane(total, 0), __builtin_amdgcn_readlane(total, 16)),
+                             max(__builtin_amdgcn_readlane(total, 32), __builtin_amdgcn_readlane(total, 48)));
+    int cnt = 0;
+    for (int base = 0; base < maxTotal; base += 64) {
+        const int nj = min(4, (maxTotal - base + 15) >> 4);                 // wave-uniform
+        if (base == 0) {
+            if (nj == 1) tk16_pass<1, false>(c, a, base, cnt, sCol, sTop);
+            else if (nj == 2) tk16_pass<2, false>(c, a, base, cnt, sCol, sTop);
+            else if (nj == 3) tk16_pass<3, false>(c, a, base, cnt, sCol, sTop);
+            else tk16_pass<4, false>(c, a, base, cnt, sCol, sTop);
+        } else {
+            if (nj <= 2) tk16_pass<2, true>(c, a, base, cnt, sCol, sTop);
+            else tk16_pass<4, true>(c, a, base, cnt, sCol, sTop);
+        }
+    }
+    if (live) {
+        const size_t o = (size_t)pair * cap + q;
+        if (l16 == 0) out_cnt[o] = cnt;
+        if (l16 < TK_K) { const uint2 e = sTop[qr][l16]; out_keys[o * TK_K + l16] = e.x == INV ? INV : e.y; }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_track_claim(const KpIn* __restrict__ kps, const uint8_t* __restrict__ desc,
                                                     const int* __restrict__ counts, int cap, const int* __restrict__ grid_start,
                                                     const int* __restrict__ grid_idx, float min_x, float min_y, float inv_w, float inv_h,
@@ -1274,20 +1455,22 @@ __global__ __launch_bounds__(64) void k_track_claim(const KpIn* __restrict__ kps
     const size_t rowBase = (size_t)pair * cap;
     const int sub = lane >> 3;                                              // the lane's query inside a group of eight
     int nm = 0, nacc = 0;
-    unsigned int key = 0xFFFFFFFFu;
-    int cnt = 0;
-    {   // first group
-        const int qi = sub;
-        if (qi < nq) { key = topKeys[(rowBase + qi) * TK_K + (lane & 7)]; cnt = topCnt[rowBase + qi]; }
-    }
+    // the lists of four groups of eight queries are in flight while one is resolved (a list comes from another XCD's writes, i.e. from
+    // memory: ~1.6 us per round trip, against ~0.2 us to resolve a group)
+    unsigned int key = 0xFFFFFFFFu, key1 = 0xFFFFFFFFu, key2 = 0xFFFFFFFFu, key3 = 0xFFFFFFFFu;
+    int cnt = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+    unsigned ob = 1, ob1 = 1, ob2 = 1, ob3 = 1;                             // != 0: the lane's query has observations (:2565: only those block a slot); raw byte, tested on use
+    auto fetch = [&](int qi, unsigned int& k_, int& c_, unsigned& o_) {
+        k_ = 0xFFFFFFFFu; c_ = 0; o_ = 1;
+        if (qi < nq) { k_ = topKeys[(rowBase + qi) * TK_K + (lane & 7)]; c_ = topCnt[rowBase + qi]; if (q_obs) o_ = q_obs[(size_t)qf * cap + qi]; }
+    };
+    fetch(sub, key, cnt, ob); fetch(8 + sub, key1, cnt1, ob1); fetch(16 + sub, key2, cnt2, ob2); fetch(24 + sub, key3, cnt3, ob3);
     for (int g0 = 0; g0 < nq; g0 += 8) {
-        // request the next group's lists before resolving this one
-        unsigned int nkey = 0xFFFFFFFFu;
-        int ncnt = 0;
-        {
-            const int qi = g0 + 8 + sub;
-            if (qi < nq) { nkey = topKeys[(rowBase + qi) * TK_K + (lane & 7)]; ncnt = topCnt[rowBase + qi]; }
-        }
+        unsigned int nkey;
+        int ncnt;
+        unsigned nob;
+        fetch(g0 + 32 + sub, nkey, ncnt, nob);
+        const unsigned long long obsMask = __ballot(ob != 0);
         const bool valid = key != 0xFFFFFFFFu;
         const unsigned int myk = key & 0xFFFFu;
         bool blocked = valid && ((blk[myk >> 5] >> (myk & 31)) & 1u);       // as of the start of the group; claims inside it: below
@@ -1297,9 +1480,9 @@ __global__ __launch_bounds__(64) void k_track_claim(const KpIn* __restrict__ kps
             const unsigned long long sel = 0xFFull << (8 * s);
             const unsigned long long bal = __ballot(valid && !blocked) & sel;
             unsigned int best = 0xFFFFFFFFu;
-            if (bal) best = (unsigned int)__shfl((int)key, __ffsll((long long)bal) - 1);
+            if (bal) best = (unsigned int)__builtin_amdgcn_readlane((int)key, __ffsll((long long)bal) - 1);   // (wave-uniform lane: no LDS crossbar round trip)
             else {
-                const int c = __shfl(cnt, 8 * s);
+                const int c = __builtin_amdgcn_readlane(cnt, 8 * s);
                 if (c > TK_K) {
                     // every listed candidate is blocked but the window holds more: scan it again with the blocked set applied
                     const KpIn kq = kps[(size_t)qf * cap + qi];
@@ -1354,17 +1537,18 @@ __global__ __launch_bounds__(64) void k_track_claim(const KpIn* __restrict__ kps
             const int d = (int)(best >> 21);
             if (d > 100) continue;                                          // TH_HIGH (:2589)
             const unsigned int k = best & 0xFFFFu, bin = (best >> 16) & 31u;
-            const bool obs = q_obs ? q_obs[(size_t)qf * cap + qi] != 0 : true;
+            const bool obs = (obsMask >> (8 * s)) & 1ull;
             if (obs && valid && myk == k) blocked = true;                  // later queries of this group see the claim
             if (lane == 0) {
+                // LDS updates as returnless atomics: nothing in the chain of the next query waits for them
                 mrow[k] = qi;
-                if (obs) blk[k >> 5] |= 1u << (k & 31);
-                if (check_ori && bin != TK_NOBIN) { acc[nacc] = k | (bin << 16); hist[bin] += 1; }
+                if (obs) atomicOr(&blk[k >> 5], 1u << (k & 31));
+                if (check_ori && bin != TK_NOBIN) { acc[nacc] = k | (bin << 16); atomicAdd(&hist[bin], 1u); }
             }
             ++nm;
             if (check_ori && bin != TK_NOBIN) ++nacc;
         }
-        key = nkey; cnt = ncnt;
+        key = key1; cnt = cnt1; ob = ob1; key1 = key2; cnt1 = cnt2; ob1 = ob2; key2 = key3; cnt2 = cnt3; ob2 = ob3; key3 = nkey; cnt3 = ncnt; ob3 = nob;
     }
     __syncthreads();
     if (check_ori) {
@@ -1401,13 +1585,6 @@ __global__ __launch_bounds__(64) void k_track_claim(const KpIn* __restrict__ kps
 // TemplatedVocabulary.h:1239-1250).  A wave instruction then touches the 3 lines of each of its 4 child blocks instead of 64 scattered
 // rows -- at ORBvoc's size (35.6 MB of node descriptors) the L1 line rate, not the arithmetic, bounds the thread-per-descriptor kernel.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned row16_min_u32(unsigned v) {
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false));   // row_ror:8
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false));   // row_ror:4
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xf, 0xf, false));   // row_ror:2
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xf, 0xf, false));   // row_ror:1
-    return v;
-}
 __global__ __launch_bounds__(256) void k_bow_transform2(const uint8_t* __restrict__ desc, int n, const unsigned* __restrict__ info,
                                                         const uint8_t* __restrict__ ndesc, const int* __restrict__ orig,
                                                         const int* __restrict__ nword, const double* __restrict__ nweight,

@@ -519,8 +519,10 @@ static int build_geometry(orbx* o, int w, int h) {
             G.lastLevel = o->strips[G.strip0 + G.nstrips - 1].level;
             G.qcap = qworst;
             if (gi < 2) {
-                const int budget = (160 * 1024 / 7 - 2 * G.tile) / (2 * (F3_NT / 64));
-                G.qcap = std::min(qworst, std::max(512, budget / 64 * 64));
+                int wgs = 7;
+                if (const char* e = ab_env("ORBX_FAST_WGS")) wgs = std::max(1, atoi(e));
+                const int budget = (160 * 1024 / wgs - 2 * G.tile) / (2 * (F3_NT / 64));
+                G.qcap = std::min(qworst, std::max(wgs > 7 ? 256 : 512, budget / 64 * 64));
             } else {
                 // coarse levels: dense corners (over half of a cell's pixels survive on the synthetic stream), so only a mild
                 // bound -- 5 workgroups per CU instead of 4 -- and only if the queue still holds >= 3/4 of the worst case

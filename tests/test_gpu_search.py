@@ -382,11 +382,12 @@ def test_device_resident_tracking_window_batch(pkg, oracle, synth):
             assert sec_d[p, q] == (int(rest.min()) if len(rest) else 256)
 
 
-@pytest.mark.parametrize("check_ori", [True, False])
-def test_batched_search_by_projection_final_matches(pkg, oracle, synth, check_ori):
+@pytest.mark.parametrize("check_ori,th", [(True, 15.0), (False, 15.0), (True, 45.0)])
+def test_batched_search_by_projection_final_matches(pkg, oracle, synth, check_ori, th):
     """M4 end to end on the device for a batch of frame pairs (claims in query order, TH_HIGH, rotation histogram + three-maxima
     cull): the final match row and count of every pair equal orbm_search_by_projection_frame (single-frame host replay) AND the
-    oracle, entry for entry.  The batch holds an EMPTY frame (both as the searched and as the searching one), pairs whose searched
+    oracle, entry for entry (th = 45: windows of more than 16 grid columns and more than 64 grid entries, i.e. several passes of the
+    16-lanes-per-query list kernel).  The batch holds an EMPTY frame (both as the searched and as the searching one), pairs whose searched
     frame has 35 % / 97 % of its slots blocked (the second drives queries through all eight listed candidates into the in-place
     rescan), queries without observations (their slot can be taken again), and a frame matched against itself (distance-0 ties)."""
     import ctypes as C
@@ -415,7 +416,7 @@ def test_batched_search_by_projection_final_matches(pkg, oracle, synth, check_or
     NP = NB - 1
     dm = pkg.DeviceBuffer(NP * cap * 4); dn = pkg.DeviceBuffer(NP * 4)
     sf = ex.GetScaleFactors()
-    dx, dy, th = 2.0, -1.0, 15.0
+    dx, dy = 2.0, -1.0
     for _ in (0,):                                                             # pair p: frame p+1 (queries) searches frame p
         rc = L.orbm_search_by_projection_batch_async(m.h, r["kps"], r["desc"], r["counts"], cap, gs.ptr, gi.ptr, 0.0, 0.0, float(inv_w), float(inv_h),
                                                      1, 0, NP, th, sf.ctypes.data_as(C.c_void_p), 8, dx, dy, dblk.ptr, dobs.ptr, int(check_ori),
