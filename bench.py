@@ -64,9 +64,9 @@ def parse_args(argv=None):
                     help="graph: the step's whole enqueue sequence is captured once and replayed with one hipGraphLaunch per step; "
                          "auto: graph from 64 frames per step on, eager below (a small step's graph is placed differently from one "
                          "instantiation to the next: 0.24 or 0.32 ms per 16-frame step, eager 0.245 every time)")
-    ap.add_argument("--match", choices=["window", "knn2"], default="knn2",
-                    help="c2/c5 match leg: 'knn2' = dense brute-force 2-NN (Frame.cc:1440-1480); 'window' = the monocular tracker's own "
-                         "matcher, SearchByProjection(frame, previous frame) with final matches on the device (Tracking.cc:3203-3211)")
+    ap.add_argument("--match", choices=["window", "knn2"], default="window",
+                    help="c2/c5 match leg: 'window' (default) = the monocular tracker's own matcher, SearchByProjection(frame, previous frame) "
+                         "with final matches on the device (Tracking.cc:3203-3211); 'knn2' = dense brute-force 2-NN (Frame.cc:1440-1480)")
     ap.add_argument("--texture", choices=["dense", "sparse", "lowcontrast", "mixed"], default="dense",
                     help="synthetic input class (orb-slam3_amd/synth.py): dense = SURVEY 8(d)'s generator (the headline; ~6 %% of the level-0 "
                          "pixels are FAST corners), sparse = camera-like density (~2 %%), lowcontrast = corners mostly below iniThFAST "

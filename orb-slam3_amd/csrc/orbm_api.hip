@@ -1151,19 +1151,23 @@ int orbm_search_by_projection_batch_async(orbm_t* m, const orbm_kp_t* kps, const
     // scratch of the handle: per query the window population and its TK_K best candidates, per pair the (slot, bin) list of the assignments
     const size_t rows = (size_t)npairs * cap;
     const size_t bCnt = (rows * sizeof(int) + 255) & ~(size_t)255, bKeys = (rows * TK_K * sizeof(unsigned) + 255) & ~(size_t)255,
-                 bAcc = (rows * sizeof(unsigned) + 255) & ~(size_t)255;
-    uint8_t* scr = batch_scratch(m, bCnt + bKeys + bAcc);
-    if (!scr) { set_merr("SearchByProjection batch scratch of %zu B unavailable (inside a capture, run the call once eagerly first)", bCnt + bKeys + bAcc); return ORBM_E_HIP; }
+                 bAcc = (rows * sizeof(unsigned) + 255) & ~(size_t)255, bEnt = rows * sizeof(uint4);
+    uint8_t* scr = batch_scratch(m, bCnt + bKeys + bAcc + bEnt);
+    if (!scr) { set_merr("SearchByProjection batch scratch of %zu B unavailable (inside a capture, run the call once eagerly first)", bCnt + bKeys + bAcc + bEnt); return ORBM_E_HIP; }
     int* topCnt = (int*)scr; unsigned* topKeys = (unsigned*)(scr + bCnt); unsigned* acc = (unsigned*)(scr + bCnt + bKeys);
+    uint4* ent = (uint4*)(scr + bCnt + bKeys + bAcc);                      // the searched frames' grid entries, packed (k_track_pack)
     const float factor = ORBM_HISTO_LENGTH / 360.0f;                        // ORBmatcher.cc:2478
-    const size_t lds = (size_t)(((cap + 31) >> 5) + 32) * sizeof(unsigned);
+    const size_t lds = (size_t)(2 * ((cap + 31) >> 5) + 32) * sizeof(unsigned);   // blocked bits, rotation histogram, observed bits
     MHIPCHK(rec_time(m, m->e0));
     if (ab_env("ORBM_TOPK_WAVE"))                                           // A/B: a wave per query
         hipLaunchKernelGGL(k_track_topk, dim3((cap + 3) / 4, npairs), dim3(256), 0, m->stream, (const KpIn*)kps, desc, counts, cap,
                            grid_start, grid_idx, min_x, min_y, inv_w, inv_h, q_first, t_first, th, st, dx, dy, factor, topCnt, topKeys);
     else
+    {
+        hipLaunchKernelGGL(k_track_pack, dim3((cap + 255) / 256, npairs), dim3(256), 0, m->stream, (const KpIn*)kps, cap, grid_start, grid_idx, t_first, ent);
         hipLaunchKernelGGL(k_track_topk16, dim3((cap + 15) / 16, npairs), dim3(256), 0, m->stream, (const KpIn*)kps, desc, counts, cap,
-                           grid_start, grid_idx, min_x, min_y, inv_w, inv_h, q_first, t_first, th, st, dx, dy, factor, topCnt, topKeys);
+                           grid_start, ent, min_x, min_y, inv_w, inv_h, q_first, t_first, th, st, dx, dy, factor, topCnt, topKeys);
+    }
     hipLaunchKernelGGL(k_track_claim, dim3(npairs), dim3(64), lds, m->stream, (const KpIn*)kps, desc, counts, cap,
                        grid_start, grid_idx, min_x, min_y, inv_w, inv_h, q_first, t_first, th, st, dx, dy, factor, topCnt, topKeys,
                        t_blocked, q_obs, check_orientation, acc, match, nmatches);

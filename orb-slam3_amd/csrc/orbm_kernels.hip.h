@@ -1262,7 +1262,7 @@ __global__ __launch_bounds__(256) void k_track_topk(const KpIn* __restrict__ kps
 // the NJ loads of every step are in flight together; consecutive queries sit on the same pyramid level (similar windows), so NJ is
 // chosen per wave.
 struct Tk16 {
-    const int* gi; const KpIn* kt; const uint8_t* dt; int cap;
+    const uint4* ent; const uint8_t* dt; int cap;
     float x, y, r, qangle, factor; int minLevel, maxLevel;
     int total, ncols, qr, l16, wr;
 };
@@ -1279,16 +1279,16 @@ __device__ __forceinline__ void tk16_pass(const Tk16& c, const u64 (&a)[4], int 
 #pragma unroll
         for (int j = 0; j < NJ; ++j) if (in && t[j] >= e.x) { off[j] = e.x; j0[j] = e.y; }
     }
+    // one 16-byte record per grid entry, in the grid's own order (k_track_pack): (x, y, angle, octave << 16 | keypoint) -- the entry and
+    // its keypoint in ONE load from consecutive addresses instead of an index and three dependent scattered ones
     int k[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) k[j] = c.gi[t[j] < c.total ? j0[j] + (t[j] - off[j]) : 0];
     float kx[NJ], ky[NJ], ang[NJ];
     int oct[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        k[j] = (int)min((unsigned)k[j], (unsigned)(c.cap - 1));              // (an unused entry's read of list slot 0 may hold anything)
-        const KpIn* kp = c.kt + k[j];
-        kx[j] = kp->x; ky[j] = kp->y; ang[j] = kp->angle; oct[j] = kp->octave;
+        const uint4 e = c.ent[t[j] < c.total ? j0[j] + (t[j] - off[j]) : 0];
+        kx[j] = __uint_as_float(e.x); ky[j] = __uint_as_float(e.y); ang[j] = __uint_as_float(e.z);
+        oct[j] = (int)(e.w >> 16); k[j] = (int)(e.w & 0xFFFFu);
     }
     bool ok[NJ];
     uint4 lo[NJ], hi[NJ];
@@ -1349,9 +1349,21 @@ __device__ __forceinline__ void tk16_pass(const Tk16& c, const u64 (&a)[4], int 
     __builtin_amdgcn_wave_barrier();
 }
 
+// k_track_pack: the searched frames' grid entries as 16-byte records in grid order (see tk16_pass)
+__global__ __launch_bounds__(256) void k_track_pack(const KpIn* __restrict__ kps, int cap, const int* __restrict__ grid_start,
+                                                    const int* __restrict__ grid_idx, int t_first, uint4* __restrict__ ent) {
+    const int pair = blockIdx.y, tf = t_first + pair;
+    const int pos = blockIdx.x * 256 + threadIdx.x;
+    const int n = min(grid_start[(size_t)tf * (64 * 48 + 1) + 64 * 48], cap);
+    if (pos >= n) return;
+    const int k = grid_idx[(size_t)tf * cap + pos];
+    const KpIn kp = kps[(size_t)tf * cap + k];
+    ent[(size_t)pair * cap + pos] = make_uint4(__float_as_uint(kp.x), __float_as_uint(kp.y), __float_as_uint(kp.angle), ((unsigned)kp.octave << 16) | (unsigned)k);
+}
+
 __global__ __launch_bounds__(256) void k_track_topk16(const KpIn* __restrict__ kps, const uint8_t* __restrict__ desc,
                                                       const int* __restrict__ counts, int cap, const int* __restrict__ grid_start,
-                                                      const int* __restrict__ grid_idx, float min_x, float min_y, float inv_w, float inv_h,
+                                                      const uint4* __restrict__ ent, float min_x, float min_y, float inv_w, float inv_h,
                                                       int q_first, int t_first, float th, ScaleTab st, float dx, float dy, float factor,
                                                       int* __restrict__ out_cnt, unsigned int* __restrict__ out_keys) {
     __shared__ int2 sCol[16][64];                                           // per query: (offset in the flattened list, first grid entry) of each window column
@@ -1400,7 +1412,7 @@ __global__ __launch_bounds__(256) void k_track_topk16(const KpIn* __restrict__ k
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                  // a row lives inside one wave: LDS traffic of the same wave is ordered
     __builtin_amdgcn_wave_barrier();
     Tk16 c;
-    c.gi = grid_idx + (size_t)tf * cap; c.kt = kps + (size_t)tf * cap; c.dt = desc + (size_t)tf * cap * 32; c.cap = cap;
+    c.ent = ent + (size_t)pair * cap; c.dt = desc + (size_t)tf * cap * 32; c.cap = cap;
     c.x = x; c.y = y; c.r = r; c.qangle = kq.angle; c.factor = factor; c.minLevel = kq.octave - 1; c.maxLevel = kq.octave + 1;
     c.total = total; c.ncols = ncols; c.qr = qr; c.l16 = l16; c.wr = wr;
     const int maxTotal = max(max(__builtin_amdgcn_readlane(total, 0), __builtin_amdgcn_readlane(total, 16)),
@@ -1432,22 +1444,40 @@ __global__ __launch_bounds__(64) void k_track_claim(const KpIn* __restrict__ kps
                                                     const int* __restrict__ topCnt, const unsigned int* __restrict__ topKeys,
                                                     const uint8_t* __restrict__ t_blocked, const uint8_t* __restrict__ q_obs, int check_ori,
                                                     unsigned int* __restrict__ accepted, int* __restrict__ match, int* __restrict__ nmatches) {
-    extern __shared__ unsigned int tk_lds[];                                // blocked bit array [ceil(cap / 32)] then hist[32]
+    extern __shared__ unsigned int tk_lds[];                                // blocked bit array [ceil(cap / 32)], hist[32], "query has observations" bits [ceil(cap / 32)]
     const int lane = threadIdx.x, pair = blockIdx.x;
     const int qf = q_first + pair, tf = t_first + pair;
     const int nq = min(counts[qf], cap), nt = min(counts[tf], cap);
     const int nwords = (cap + 31) >> 5;
     unsigned int* blk = tk_lds;
     unsigned int* hist = tk_lds + nwords;
+    unsigned int* obsb = hist + 32;
     int* mrow = match + (size_t)pair * cap;
     unsigned int* acc = accepted + (size_t)pair * cap;
     for (int w = lane; w < nwords; w += 64) {
         unsigned int bits = 0;
         if (t_blocked) {
-            const uint8_t* tb = t_blocked + (size_t)tf * cap + (size_t)w * 32;
-            for (int b = 0; b < 32; ++b) if (w * 32 + b < nt && tb[b]) bits |= 1u << b;
+            const uint8_t* tb = t_blocked + (size_t)tf * cap;
+            const int last = max(nt - 1, 0);
+            unsigned v[32];                                                 // 32 byte loads in flight (clamped, not predicated), then the bits
+#pragma unroll
+            for (int b = 0; b < 32; ++b) v[b] = tb[min(w * 32 + b, last)];
+#pragma unroll
+            for (int b = 0; b < 32; ++b) if (w * 32 + b < nt && v[b]) bits |= 1u << b;
         }
         blk[w] = bits;
+        unsigned int ob = 0xFFFFFFFFu;                                      // q_obs absent: every query counts as observed
+        if (q_obs) {
+            const uint8_t* qo = q_obs + (size_t)qf * cap;
+            const int last = max(nq - 1, 0);
+            unsigned v[32];
+#pragma unroll
+            for (int b = 0; b < 32; ++b) v[b] = qo[min(w * 32 + b, last)];
+            ob = 0;
+#pragma unroll
+            for (int b = 0; b < 32; ++b) if (v[b]) ob |= 1u << b;
+        }
+        obsb[w] = ob;
     }
     if (lane < 32) hist[lane] = 0;
     for (int k = lane; k < cap; k += 64) mrow[k] = -1;                        // ORBM_NO_MATCH
@@ -1455,26 +1485,73 @@ __global__ __launch_bounds__(64) void k_track_claim(const KpIn* __restrict__ kps
     const size_t rowBase = (size_t)pair * cap;
     const int sub = lane >> 3;                                              // the lane's query inside a group of eight
     int nm = 0, nacc = 0;
-    // the lists of four groups of eight queries are in flight while one is resolved (a list comes from another XCD's writes, i.e. from
-    // memory: ~1.6 us per round trip, against ~0.2 us to resolve a group)
-    unsigned int key = 0xFFFFFFFFu, key1 = 0xFFFFFFFFu, key2 = 0xFFFFFFFFu, key3 = 0xFFFFFFFFu;
-    int cnt = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
-    unsigned ob = 1, ob1 = 1, ob2 = 1, ob3 = 1;                             // != 0: the lane's query has observations (:2565: only those block a slot); raw byte, tested on use
-    auto fetch = [&](int qi, unsigned int& k_, int& c_, unsigned& o_) {
-        k_ = 0xFFFFFFFFu; c_ = 0; o_ = 1;
-        if (qi < nq) { k_ = topKeys[(rowBase + qi) * TK_K + (lane & 7)]; c_ = topCnt[rowBase + qi]; if (q_obs) o_ = q_obs[(size_t)qf * cap + qi]; }
+    // Two register sets of four groups (32 queries) each: set A is resolved while set B's lists are in flight (a list comes from another
+    // XCD's writes, i.e. from memory: ~1.6 us per round trip, against ~0.3 us to resolve a group).  The loaded values are touched only
+    // when their set becomes current -- a move or a select behind the load would make the wave wait for it there -- and the loads are
+    // UNCONDITIONAL (clamped index): a load under a branch turns every later s_waitcnt into a full drain.
+    const int qLast = max(nq - 1, 0);
+    unsigned int ak0, ak1, ak2, ak3;
+    int ac0, ac1, ac2, ac3;
+    auto fetch = [&](int qi, unsigned int& k_, int& c_) {
+        const int qc = min(qi, qLast);
+        k_ = topKeys[(rowBase + qc) * TK_K + (lane & 7)];
+        c_ = topCnt[rowBase + qc];
     };
-    fetch(sub, key, cnt, ob); fetch(8 + sub, key1, cnt1, ob1); fetch(16 + sub, key2, cnt2, ob2); fetch(24 + sub, key3, cnt3, ob3);
-    for (int g0 = 0; g0 < nq; g0 += 8) {
-        unsigned int nkey;
-        int ncnt;
-        unsigned nob;
-        fetch(g0 + 32 + sub, nkey, ncnt, nob);
+    fetch(sub, ak0, ac0); fetch(8 + sub, ak1, ac1); fetch(16 + sub, ak2, ac2); fetch(24 + sub, ak3, ac3);
+    for (int G = 0; G < nq; G += 32) {
+      unsigned int bk0, bk1, bk2, bk3;
+      int bc0, bc1, bc2, bc3;
+      fetch(G + 32 + sub, bk0, bc0); fetch(G + 40 + sub, bk1, bc1); fetch(G + 48 + sub, bk2, bc2); fetch(G + 56 + sub, bk3, bc3);
+#pragma clang loop unroll(disable)
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int g0 = G + 8 * s4;
+        if (g0 >= nq) break;
+        const bool ql = g0 + sub < nq;
+        const unsigned int kraw = s4 == 0 ? ak0 : s4 == 1 ? ak1 : s4 == 2 ? ak2 : ak3;
+        const int craw = s4 == 0 ? ac0 : s4 == 1 ? ac1 : s4 == 2 ? ac2 : ac3;
+        const unsigned int key = ql ? kraw : 0xFFFFFFFFu;
+        const int cnt = ql ? craw : 0;
+        const int qme = min(g0 + sub, qLast);
+        const unsigned ob = (obsb[qme >> 5] >> (qme & 31)) & 1u;               // != 0: the lane's query has observations (:2565: only those block a slot)
         const unsigned long long obsMask = __ballot(ob != 0);
         const bool valid = key != 0xFFFFFFFFu;
         const unsigned int myk = key & 0xFFFFu;
         bool blocked = valid && ((blk[myk >> 5] >> (myk & 31)) & 1u);       // as of the start of the group; claims inside it: below
         const int gend = min(8, nq - g0);
+        {   // all eight queries at once: each takes the first of its listed candidates that was free when the group started.  That IS the
+            // sequential outcome unless two accepted queries of the group want the same slot (the later one must then see the claim, or
+            // overwrite it) or a query has run out of listed candidates with more in its window -- such a group is replayed one by one.
+            const unsigned long long fr = __ballot(valid && !blocked);
+            const unsigned m8 = (unsigned)(fr >> (8 * sub)) & 0xFFu;
+            const unsigned pick = (unsigned)__shfl((int)key, (sub << 3) + (m8 ? __ffs((int)m8) - 1 : 0));
+            const bool qlive = g0 + sub < nq;
+            const bool take = qlive && m8 != 0 && (pick >> 21) <= 100u;    // TH_HIGH (:2589)
+            const unsigned pk = pick & 0xFFFFu;
+            bool clash = qlive && m8 == 0 && cnt > TK_K;
+#pragma unroll
+            for (int e = 0; e < 7; ++e) {
+                const unsigned ke = (unsigned)__builtin_amdgcn_readlane((int)pk, 8 * e);
+                const int te = __builtin_amdgcn_readlane((int)take, 8 * e);
+                if (te && take && sub > e && ke == pk) clash = true;
+            }
+            if (!__any(clash)) {
+                const bool lead = (lane & 7) == 0 && take;
+                const unsigned bin = (pick >> 16) & 31u;
+                const bool withBin = lead && check_ori && bin != TK_NOBIN;
+                const unsigned long long tb = __ballot(lead), bb = __ballot(withBin);
+                if (lead) {
+                    mrow[pk] = g0 + sub;
+                    if (ob != 0) atomicOr(&blk[pk >> 5], 1u << (pk & 31));
+                }
+                if (withBin) {
+                    acc[nacc + __popcll(bb & ((1ull << lane) - 1ull))] = pk | (bin << 16);
+                    atomicAdd(&hist[bin], 1u);
+                }
+                nm += __popcll(tb);
+                nacc += __popcll(bb);
+                continue;
+            }
+        }
         for (int s = 0; s < gend; ++s) {
             const int qi = g0 + s;
             const unsigned long long sel = 0xFFull << (8 * s);
@@ -1548,7 +1625,8 @@ __global__ __launch_bounds__(64) void k_track_claim(const KpIn* __restrict__ kps
             ++nm;
             if (check_ori && bin != TK_NOBIN) ++nacc;
         }
-        key = key1; cnt = cnt1; ob = ob1; key1 = key2; cnt1 = cnt2; ob1 = ob2; key2 = key3; cnt2 = cnt3; ob2 = ob3; key3 = nkey; cnt3 = ncnt; ob3 = nob;
+      }
+      ak0 = bk0; ak1 = bk1; ak2 = bk2; ak3 = bk3; ac0 = bc0; ac1 = bc1; ac2 = bc2; ac3 = bc3;
     }
     __syncthreads();
     if (check_ori) {

@@ -4,13 +4,15 @@ set -o pipefail
 out=$GRAFT_REPO_ROOT/gpurun_out/refresh3; mkdir -p $out
 if [ "$1" = bench ]; then
   python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r03_bench_c2.json 2> $out/bench_c2.err; tail -c 200 $out/r03_bench_c2.json; echo
-  python bench.py --steps 20 --warmup 5 --match window > $out/r03_bench_c2_window.json 2> $out/bench_c2w.err; tail -c 200 $out/r03_bench_c2_window.json; echo
+  python bench.py --steps 20 --warmup 5 --match knn2 > $out/r03_bench_c2_knn2.json 2> $out/bench_c2k.err; tail -c 200 $out/r03_bench_c2_knn2.json; echo
+  for t in sparse lowcontrast mixed; do python bench.py --steps 20 --warmup 5 --texture $t --distinct 48 > $out/r03_bench_c2_$t.json 2> $out/bench_c2_$t.err; tail -c 200 $out/r03_bench_c2_$t.json; echo; done
+  python bench.py --steps 20 --warmup 5 --distinct 48 > $out/r03_bench_c2_dense.json 2> $out/bench_c2_dense.err; tail -c 200 $out/r03_bench_c2_dense.json; echo
   for c in c3 c4 c5; do python bench.py --config $c --steps 20 --warmup 5 > $out/r03_bench_$c.json 2> $out/bench_$c.err; tail -c 200 $out/r03_bench_$c.json; echo; done
   python bench.py --config c4 --batch 512 --steps 20 --warmup 5 > $out/r03_bench_c4_b512.json 2> $out/bench_c4b.err; tail -c 200 $out/r03_bench_c4_b512.json; echo
   python tools/latency_breakdown.py > $out/r03_latency.txt 2>&1; tail -5 $out/r03_latency.txt
 else
   for c in c2 c3 c4 c5; do bash tools/prof.sh refresh3/prof_$c --config $c > $out/prof_$c.txt 2>&1; cp $GRAFT_REPO_ROOT/gpurun_out/refresh3/prof_${c}_kernel_stats.csv $out/r03_kernel_stats_$c.csv 2>/dev/null; echo prof $c done; done
-  bash tools/prof.sh refresh3/prof_c2w --match window > $out/prof_c2w.txt 2>&1; cp $GRAFT_REPO_ROOT/gpurun_out/refresh3/prof_c2w_kernel_stats.csv $out/r03_kernel_stats_c2_window.csv 2>/dev/null; echo prof c2 window done
+  bash tools/prof.sh refresh3/prof_c2k --match knn2 > $out/prof_c2k.txt 2>&1; cp $GRAFT_REPO_ROOT/gpurun_out/refresh3/prof_c2k_kernel_stats.csv $out/r03_kernel_stats_c2_knn2.csv 2>/dev/null; echo prof c2 knn2 done
   bash tools/prof.sh refresh3/prof_c2s --texture sparse --distinct 48 > $out/prof_c2s.txt 2>&1; cp $GRAFT_REPO_ROOT/gpurun_out/refresh3/prof_c2s_kernel_stats.csv $out/r03_kernel_stats_c2_sparse.csv 2>/dev/null; echo prof c2 sparse done
   PMC_BENCH_ARGS="--config c5 --batch 16" bash tools/pmc.sh refresh3/pmc_fetch_c5 FETCH_SIZE > $out/pmc_fetch_c5.txt 2>&1 && echo fetch c5 done
   PMC_BENCH_ARGS="--config c5 --batch 16" bash tools/pmc.sh refresh3/pmc_write_c5 WRITE_SIZE > $out/pmc_write_c5.txt 2>&1 && echo write c5 done
