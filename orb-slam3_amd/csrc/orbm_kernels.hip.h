@@ -1267,17 +1267,29 @@ struct Tk16 {
     int total, ncols, qr, l16, wr;
 };
 template <int NJ, bool FB>
-__device__ __forceinline__ void tk16_pass(const Tk16& c, const u64 (&a)[4], int base, int& cnt, const int2 (*sCol)[64], uint2 (*sTop)[TK_K]) {
+__device__ __forceinline__ void tk16_pass(const Tk16& c, const u64 (&a)[4], int base, int& cnt, const int2 (*sCol)[64], const int (*sAdj)[64], uint2 (*sK)[16], uint2 (*sTop)[TK_K]) {
     const unsigned INV = 0xFFFFFFFFu;
-    int t[NJ], off[NJ], j0[NJ];
+    int t[NJ], eidx[NJ];
+    const int cnt0 = cnt;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) { t[j] = base + 16 * j + c.l16; off[j] = 0; j0[j] = 0; }
-    // each entry's column: the last one whose offset is <= t (columns ascending, empty ones share an offset)
-    for (int col = 0; __any(col < c.ncols); ++col) {
-        const int2 e = sCol[c.qr][col];
-        const bool in = col < c.ncols;
+    for (int j = 0; j < NJ; ++j) t[j] = base + 16 * j + c.l16;
+    if (!FB) {
+        // first 64 entries of a window: the prologue left (grid position - list position) of every entry in LDS
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) if (in && t[j] >= e.x) { off[j] = e.x; j0[j] = e.y; }
+        for (int j = 0; j < NJ; ++j) eidx[j] = t[j] < c.total ? t[j] + sAdj[c.qr][t[j]] : 0;
+    } else {
+        // later passes: each entry's column is the last one whose offset is <= t (columns ascending, empty ones share an offset)
+        int off[NJ], j0[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { off[j] = 0; j0[j] = 0; }
+        for (int col = 0; __any(col < c.ncols); ++col) {
+            const int2 e = sCol[c.qr][col];
+            const bool in = col < c.ncols;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) if (in && t[j] >= e.x) { off[j] = e.x; j0[j] = e.y; }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) eidx[j] = t[j] < c.total ? j0[j] + (t[j] - off[j]) : 0;
     }
     // one 16-byte record per grid entry, in the grid's own order (k_track_pack): (x, y, angle, octave << 16 | keypoint) -- the entry and
     // its keypoint in ONE load from consecutive addresses instead of an index and three dependent scattered ones
@@ -1286,7 +1298,7 @@ __device__ __forceinline__ void tk16_pass(const Tk16& c, const u64 (&a)[4], int 
     int oct[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const uint4 e = c.ent[t[j] < c.total ? j0[j] + (t[j] - off[j]) : 0];
+        const uint4 e = c.ent[eidx[j]];
         kx[j] = __uint_as_float(e.x); ky[j] = __uint_as_float(e.y); ang[j] = __uint_as_float(e.z);
         oct[j] = (int)(e.w >> 16); k[j] = (int)(e.w & 0xFFFFu);
     }
@@ -1300,10 +1312,12 @@ __device__ __forceinline__ void tk16_pass(const Tk16& c, const u64 (&a)[4], int 
     }
     const unsigned below = (1u << c.l16) - 1u;
     unsigned key[NJ + 1], word[NJ + 1];
+    int posj[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const unsigned rowbits = (unsigned)(__ballot(ok[j]) >> (16 * c.wr)) & 0xFFFFu;
         const int pos = cnt + __popc(rowbits & below);
+        posj[j] = pos;
         const int d = ham256(a, (u64)lo[j].x | ((u64)lo[j].y << 32), (u64)lo[j].z | ((u64)lo[j].w << 32),
                              (u64)hi[j].x | ((u64)hi[j].y << 32), (u64)hi[j].z | ((u64)hi[j].w << 32));
         float rot = c.qangle - ang[j];
@@ -1317,16 +1331,28 @@ __device__ __forceinline__ void tk16_pass(const Tk16& c, const u64 (&a)[4], int 
     }
     key[NJ] = INV; word[NJ] = INV;
     if (FB && c.l16 < TK_K) { const uint2 pv = sTop[c.qr][c.l16]; key[NJ] = pv.x; word[NJ] = pv.y; }   // the list so far competes again
-    if (NJ == 1 && !FB) {
-        // one key per lane: its rank = the number of smaller keys in the row (15 rotations; keys are unique by position)
+    // !FB: at most 16 candidates of a row passed the tests (the rule: 14 grid entries per window, a quarter of them on the right levels
+    // and inside the window): they are packed to one per lane -- in visiting order -- and each lane's rank is the number of smaller
+    // keys in its row (15 rotations; keys are unique by position).  Otherwise eight row-wide minimum reductions.
+    const int nv = cnt - cnt0;
+    if (!FB && (NJ == 1 || !__any(nv > 16))) {
+        unsigned k1 = key[0], w1 = word[0];
+        if (NJ > 1) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) if (key[j] != INV) sK[c.qr][posj[j] - cnt0] = make_uint2(key[j], word[j]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint2 e = sK[c.qr][c.l16];
+            k1 = c.l16 < nv ? e.x : INV; w1 = e.y;
+        }
         int rank = 0;
-        unsigned rk = key[0];
+        unsigned rk = k1;
 #pragma unroll
         for (int i = 0; i < 15; ++i) {
             rk = (unsigned)__builtin_amdgcn_update_dpp((int)rk, (int)rk, 0x121, 0xf, 0xf, false);   // row_ror:1
-            rank += rk < key[0] ? 1 : 0;
+            rank += rk < k1 ? 1 : 0;
         }
-        if (key[0] != INV && rank < TK_K) sTop[c.qr][rank] = make_uint2(key[0], word[0]);
+        if (k1 != INV && rank < TK_K) sTop[c.qr][rank] = make_uint2(k1, w1);
     } else {
 #pragma unroll
         for (int i = 0; i < TK_K; ++i) {
@@ -1368,6 +1394,8 @@ __global__ __launch_bounds__(256) void k_track_topk16(const KpIn* __restrict__ k
                                                       int* __restrict__ out_cnt, unsigned int* __restrict__ out_keys) {
     __shared__ int2 sCol[16][64];                                           // per query: (offset in the flattened list, first grid entry) of each window column
     __shared__ uint2 sTop[16][TK_K];                                        // per query: (distance << 16 | position, output word), ascending
+    __shared__ int sAdj[16][64];                                            // per query: grid position - list position of the first 64 window entries
+    __shared__ uint2 sK[16][16];                                            // per query: the candidates that passed, one per lane
     const int lane = threadIdx.x & 63, l16 = threadIdx.x & 15, wr = lane >> 4, qr = threadIdx.x >> 4;
     const int pair = blockIdx.y;
     const int qf = q_first + pair, tf = t_first + pair;
@@ -1404,7 +1432,10 @@ __global__ __launch_bounds__(256) void k_track_topk16(const KpIn* __restrict__ k
         sc += __builtin_amdgcn_update_dpp(0, sc, 0x112, 0xf, 0xf, true);
         sc += __builtin_amdgcn_update_dpp(0, sc, 0x114, 0xf, 0xf, true);
         sc += __builtin_amdgcn_update_dpp(0, sc, 0x118, 0xf, 0xf, true);
-        if (c < ncols) sCol[qr][c] = make_int2(total + sc - clen, cj0);
+        const int excl = total + sc - clen;
+        if (c < ncols) sCol[qr][c] = make_int2(excl, cj0);
+        for (int e = 0; __any(e < clen && excl + e < 64); ++e)              // (a cell column of a window holds one or two entries as a rule)
+            if (e < clen && excl + e < 64) sAdj[qr][excl + e] = cj0 - excl;
         const int s0 = __builtin_amdgcn_readlane(sc, 15), s1 = __builtin_amdgcn_readlane(sc, 31),
                   s2 = __builtin_amdgcn_readlane(sc, 47), s3 = __builtin_amdgcn_readlane(sc, 63);
         total += wr == 0 ? s0 : wr == 1 ? s1 : wr == 2 ? s2 : s3;
@@ -1421,13 +1452,13 @@ __global__ __launch_bounds__(256) void k_track_topk16(const KpIn* __restrict__ k
     for (int base = 0; base < maxTotal; base += 64) {
         const int nj = min(4, (maxTotal - base + 15) >> 4);                 // wave-uniform
         if (base == 0) {
-            if (nj == 1) tk16_pass<1, false>(c, a, base, cnt, sCol, sTop);
-            else if (nj == 2) tk16_pass<2, false>(c, a, base, cnt, sCol, sTop);
-            else if (nj == 3) tk16_pass<3, false>(c, a, base, cnt, sCol, sTop);
-            else tk16_pass<4, false>(c, a, base, cnt, sCol, sTop);
+            if (nj == 1) tk16_pass<1, false>(c, a, base, cnt, sCol, sAdj, sK, sTop);
+            else if (nj == 2) tk16_pass<2, false>(c, a, base, cnt, sCol, sAdj, sK, sTop);
+            else if (nj == 3) tk16_pass<3, false>(c, a, base, cnt, sCol, sAdj, sK, sTop);
+            else tk16_pass<4, false>(c, a, base, cnt, sCol, sAdj, sK, sTop);
         } else {
-            if (nj <= 2) tk16_pass<2, true>(c, a, base, cnt, sCol, sTop);
-            else tk16_pass<4, true>(c, a, base, cnt, sCol, sTop);
+            if (nj <= 2) tk16_pass<2, true>(c, a, base, cnt, sCol, sAdj, sK, sTop);
+            else tk16_pass<4, true>(c, a, base, cnt, sCol, sAdj, sK, sTop);
         }
     }
     if (live) {
