@@ -1157,18 +1157,28 @@ int orbm_search_by_projection_batch_async(orbm_t* m, const orbm_kp_t* kps, const
     int* topCnt = (int*)scr; unsigned* topKeys = (unsigned*)(scr + bCnt); unsigned* acc = (unsigned*)(scr + bCnt + bKeys);
     uint4* ent = (uint4*)(scr + bCnt + bKeys + bAcc);                      // the searched frames' grid entries, packed (k_track_pack)
     const float factor = ORBM_HISTO_LENGTH / 360.0f;                        // ORBmatcher.cc:2478
-    const size_t lds = (size_t)(2 * ((cap + 31) >> 5) + 32) * sizeof(unsigned);   // blocked bits, rotation histogram, observed bits
+    const size_t lds = (size_t)(2 * ((cap + 31) >> 5) + 32 + cap) * sizeof(unsigned);   // blocked bits, rotation histogram, observed bits, proposal tags
+    if (lds > 64 * 1024) { set_merr("SearchByProjection batch: %d keypoint slots per frame need %zu B of LDS (limit 64 KB, ~16 000 slots)", cap, lds); return ORBM_E_INVALID; }
     MHIPCHK(rec_time(m, m->e0));
+#ifdef ORBX_AB
     if (ab_env("ORBM_TOPK_WAVE"))                                           // A/B: a wave per query
         hipLaunchKernelGGL(k_track_topk, dim3((cap + 3) / 4, npairs), dim3(256), 0, m->stream, (const KpIn*)kps, desc, counts, cap,
                            grid_start, grid_idx, min_x, min_y, inv_w, inv_h, q_first, t_first, th, st, dx, dy, factor, topCnt, topKeys);
     else
+#endif
     {
         hipLaunchKernelGGL(k_track_pack, dim3((cap + 255) / 256, npairs), dim3(256), 0, m->stream, (const KpIn*)kps, cap, grid_start, grid_idx, t_first, ent);
         hipLaunchKernelGGL(k_track_topk16, dim3((cap + 15) / 16, npairs), dim3(256), 0, m->stream, (const KpIn*)kps, desc, counts, cap,
                            grid_start, ent, min_x, min_y, inv_w, inv_h, q_first, t_first, th, st, dx, dy, factor, topCnt, topKeys);
     }
-    hipLaunchKernelGGL(k_track_claim, dim3(npairs), dim3(64), lds, m->stream, (const KpIn*)kps, desc, counts, cap,
+#ifdef ORBX_AB
+    if (ab_env("ORBM_CLAIM_V1"))                                            // A/B: eight queries per step
+        hipLaunchKernelGGL(k_track_claim, dim3(npairs), dim3(64), lds, m->stream, (const KpIn*)kps, desc, counts, cap,
+                           grid_start, grid_idx, min_x, min_y, inv_w, inv_h, q_first, t_first, th, st, dx, dy, factor, topCnt, topKeys,
+                           t_blocked, q_obs, check_orientation, acc, match, nmatches);
+    else
+#endif
+    hipLaunchKernelGGL(k_track_claim64, dim3(npairs), dim3(64), lds, m->stream, (const KpIn*)kps, desc, counts, cap,
                        grid_start, grid_idx, min_x, min_y, inv_w, inv_h, q_first, t_first, th, st, dx, dy, factor, topCnt, topKeys,
                        t_blocked, q_obs, check_orientation, acc, match, nmatches);
     MHIPCHK(rec_time(m, m->e1));

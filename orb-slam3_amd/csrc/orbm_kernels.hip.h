@@ -1132,6 +1132,7 @@ __device__ __forceinline__ int wave_excl_scan(int v, int* total) {           // 
     *total = __builtin_amdgcn_readlane(s, 63);
     return s - v;
 }
+#ifdef ORBX_AB   /* A/B reference (a wave per query), not in the product library */
 // The window's grid columns are flattened into ONE candidate list (column starts / lengths loaded by one lane each, prefix sum across
 // lanes), so that a window of up to 64 candidates costs four dependent round trips (cell ranges, indices, keypoints, descriptors)
 // whatever its shape -- the per-column loop of k_track_window pays them per column -- and the eight best come out of eight DPP
@@ -1251,6 +1252,8 @@ __global__ __launch_bounds__(256) void k_track_topk(const KpIn* __restrict__ kps
             out_keys[o * TK_K + i] = topKey[i] == INV ? 0xFFFFFFFFu : ((topKey[i] >> 16) << 21) | (topPay[i] & 0x1FFFFFu);
     }
 }
+
+#endif  /* ORBX_AB */
 
 // k_track_topk16: the same lists with SIXTEEN lanes per query (four queries per wave).  A mono window (th = 15) holds 6 grid entries at
 // level 0 and ~40 at level 7 (14 on average over a 1000-feature frame), so a wave per query keeps most lanes idle and the kernel is bound
@@ -1468,6 +1471,61 @@ __global__ __launch_bounds__(256) void k_track_topk16(const KpIn* __restrict__ k
     }
 }
 
+// every listed candidate of query qi is blocked but its window holds more: the window again, blocked set applied (all 64 lanes; qi wave-uniform).
+// Returns the best candidate as distance << 21 | rotation bin << 16 | keypoint, or 0xFFFFFFFF.
+__device__ __forceinline__ unsigned int tk_rescan(const KpIn* __restrict__ kps, const uint8_t* __restrict__ desc, int cap, const int* __restrict__ grid_start,
+                                                  const int* __restrict__ grid_idx, float min_x, float min_y, float inv_w, float inv_h, int qf, int tf, int qi,
+                                                  float th, const ScaleTab& st, float dx, float dy, float factor, const unsigned int* blk, int lane) {
+// every listed candidate is blocked but the window holds more: scan it again with the blocked set applied
+    const KpIn kq = kps[(size_t)qf * cap + qi];
+    const KpIn* kt = kps + (size_t)tf * cap;
+    const uint8_t* dt = desc + (size_t)tf * cap * 32;
+    const int* gs = grid_start + (size_t)tf * (64 * 48 + 1);
+    const int* gi = grid_idx + (size_t)tf * cap;
+    const float x = kq.x + dx, y = kq.y + dy, r = th * st.sf[kq.octave];
+    const int minLevel = kq.octave - 1, maxLevel = kq.octave + 1;
+    const int nMinCellX = max(0, (int)floorf((x - min_x - r) * inv_w));
+    const int nMaxCellX = min(63, (int)ceilf((x - min_x + r) * inv_w));
+    const int nMinCellY = max(0, (int)floorf((y - min_y - r) * inv_h));
+    const int nMaxCellY = min(47, (int)ceilf((y - min_y + r) * inv_h));
+    const uint4* qp = (const uint4*)(desc + ((size_t)qf * cap + qi) * 32);
+    const uint4 qlo = qp[0], qhi = qp[1];
+    const u64 a[4] = {(u64)qlo.x | ((u64)qlo.y << 32), (u64)qlo.z | ((u64)qlo.w << 32),
+                      (u64)qhi.x | ((u64)qhi.y << 32), (u64)qhi.z | ((u64)qhi.w << 32)};
+    u64 bk = ~0ull;
+    int ord0 = 0;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ++ix) {
+        const int j0 = gs[ix * 48 + nMinCellY], j1 = gs[ix * 48 + nMaxCellY + 1];
+        for (int jb = j0; jb < j1; jb += 64) {
+            const int j = jb + lane;
+            if (j < j1) {
+                const int k = gi[j];
+                const KpIn kp = kt[k];
+                bool ok = !(kp.octave < minLevel) && !(kp.octave > maxLevel);
+                if (!(fabsf(kp.x - x) < r && fabsf(kp.y - y) < r)) ok = false;
+                if (ok && !((blk[k >> 5] >> (k & 31)) & 1u)) {
+                    const uint4* tp = (const uint4*)(dt + (size_t)k * 32);
+                    const uint4 lo = tp[0], hi = tp[1];
+                    const int d = ham256(a, (u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
+                                         (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32));
+                    float rot = kq.angle - kp.angle;
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == 30) bin = 0;
+                    if (bin < 0 || bin >= 30) bin = TK_NOBIN;
+                    // (order among grid entries, not among window members: monotone in it, which is all the first-minimum rule needs)
+                    const u64 kk = ((u64)d << 44) | ((u64)(ord0 + (j - j0)) << 24) | ((u64)bin << 16) | (u64)k;
+                    bk = kk < bk ? kk : bk;
+                }
+            }
+        }
+        ord0 += j1 - j0;
+    }
+    bk = wave_min_u64(bk);
+    return bk != ~0ull ? ((unsigned)(bk >> 44) << 21) | (unsigned)(bk & 0x1FFFFFu) : 0xFFFFFFFFu;
+}
+
+#ifdef ORBX_AB   /* A/B reference (eight queries per step), not in the product library */
 __global__ __launch_bounds__(64) void k_track_claim(const KpIn* __restrict__ kps, const uint8_t* __restrict__ desc,
                                                     const int* __restrict__ counts, int cap, const int* __restrict__ grid_start,
                                                     const int* __restrict__ grid_idx, float min_x, float min_y, float inv_w, float inv_h,
@@ -1592,53 +1650,7 @@ __global__ __launch_bounds__(64) void k_track_claim(const KpIn* __restrict__ kps
             else {
                 const int c = __builtin_amdgcn_readlane(cnt, 8 * s);
                 if (c > TK_K) {
-                    // every listed candidate is blocked but the window holds more: scan it again with the blocked set applied
-                    const KpIn kq = kps[(size_t)qf * cap + qi];
-                    const KpIn* kt = kps + (size_t)tf * cap;
-                    const uint8_t* dt = desc + (size_t)tf * cap * 32;
-                    const int* gs = grid_start + (size_t)tf * (64 * 48 + 1);
-                    const int* gi = grid_idx + (size_t)tf * cap;
-                    const float x = kq.x + dx, y = kq.y + dy, r = th * st.sf[kq.octave];
-                    const int minLevel = kq.octave - 1, maxLevel = kq.octave + 1;
-                    const int nMinCellX = max(0, (int)floorf((x - min_x - r) * inv_w));
-                    const int nMaxCellX = min(63, (int)ceilf((x - min_x + r) * inv_w));
-                    const int nMinCellY = max(0, (int)floorf((y - min_y - r) * inv_h));
-                    const int nMaxCellY = min(47, (int)ceilf((y - min_y + r) * inv_h));
-                    const uint4* qp = (const uint4*)(desc + ((size_t)qf * cap + qi) * 32);
-                    const uint4 qlo = qp[0], qhi = qp[1];
-                    const u64 a[4] = {(u64)qlo.x | ((u64)qlo.y << 32), (u64)qlo.z | ((u64)qlo.w << 32),
-                                      (u64)qhi.x | ((u64)qhi.y << 32), (u64)qhi.z | ((u64)qhi.w << 32)};
-                    u64 bk = ~0ull;
-                    int ord0 = 0;
-                    for (int ix = nMinCellX; ix <= nMaxCellX; ++ix) {
-                        const int j0 = gs[ix * 48 + nMinCellY], j1 = gs[ix * 48 + nMaxCellY + 1];
-                        for (int jb = j0; jb < j1; jb += 64) {
-                            const int j = jb + lane;
-                            if (j < j1) {
-                                const int k = gi[j];
-                                const KpIn kp = kt[k];
-                                bool ok = !(kp.octave < minLevel) && !(kp.octave > maxLevel);
-                                if (!(fabsf(kp.x - x) < r && fabsf(kp.y - y) < r)) ok = false;
-                                if (ok && !((blk[k >> 5] >> (k & 31)) & 1u)) {
-                                    const uint4* tp = (const uint4*)(dt + (size_t)k * 32);
-                                    const uint4 lo = tp[0], hi = tp[1];
-                                    const int d = ham256(a, (u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
-                                                         (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32));
-                                    float rot = kq.angle - kp.angle;
-                                    if (rot < 0.0f) rot += 360.0f;
-                                    int bin = (int)roundf(rot * factor);
-                                    if (bin == 30) bin = 0;
-                                    if (bin < 0 || bin >= 30) bin = TK_NOBIN;
-                                    // (order among grid entries, not among window members: monotone in it, which is all the first-minimum rule needs)
-                                    const u64 kk = ((u64)d << 44) | ((u64)(ord0 + (j - j0)) << 24) | ((u64)bin << 16) | (u64)k;
-                                    bk = kk < bk ? kk : bk;
-                                }
-                            }
-                        }
-                        ord0 += j1 - j0;
-                    }
-                    bk = wave_min_u64(bk);
-                    if (bk != ~0ull) best = ((unsigned)(bk >> 44) << 21) | (unsigned)(bk & 0x1FFFFFu);
+                    best = tk_rescan(kps, desc, cap, grid_start, grid_idx, min_x, min_y, inv_w, inv_h, qf, tf, qi, th, st, dx, dy, factor, blk, lane);
                 }
             }
             if (best == 0xFFFFFFFFu) continue;
@@ -1658,6 +1670,179 @@ __global__ __launch_bounds__(64) void k_track_claim(const KpIn* __restrict__ kps
         }
       }
       ak0 = bk0; ak1 = bk1; ak2 = bk2; ak3 = bk3; ac0 = bc0; ac1 = bc1; ac2 = bc2; ac3 = bc3;
+    }
+    __syncthreads();
+    if (check_ori) {
+        // ComputeThreeMaxima (ORBmatcher.cc:2870-2909) on the bin counts, then every assignment of the other bins is cleared (:2696-2707)
+        int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+        for (int i = 0; i < 30; ++i) {
+            const int sz = (int)hist[i];
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = i; }
+            else if (sz > max3) { max3 = sz; i3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) i3 = -1;
+        int pruned = 0;
+        for (int e = lane; e < nacc; e += 64) {
+            const unsigned int v = acc[e];
+            const int bin = (int)(v >> 16), k = (int)(v & 0xFFFFu);
+            if (bin != i1 && bin != i2 && bin != i3) { mrow[k] = -2; ++pruned; }      // ORBM_MATCH_PRUNED
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pruned += __shfl_xor(pruned, o);
+        nm -= pruned;
+    }
+    if (lane == 0) nmatches[pair] = nm;
+}
+
+#endif  /* ORBX_AB */
+
+__global__ __launch_bounds__(64) void k_track_claim64(const KpIn* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                    const int* __restrict__ counts, int cap, const int* __restrict__ grid_start,
+                                                    const int* __restrict__ grid_idx, float min_x, float min_y, float inv_w, float inv_h,
+                                                    int q_first, int t_first, float th, ScaleTab st, float dx, float dy, float factor,
+                                                    const int* __restrict__ topCnt, const unsigned int* __restrict__ topKeys,
+                                                    const uint8_t* __restrict__ t_blocked, const uint8_t* __restrict__ q_obs, int check_ori,
+                                                    unsigned int* __restrict__ accepted, int* __restrict__ match, int* __restrict__ nmatches) {
+    extern __shared__ unsigned int tk_lds[];                                // blocked bit array [ceil(cap / 32)], hist[32], "query has observations" bits [ceil(cap / 32)]
+    const int lane = threadIdx.x, pair = blockIdx.x;
+    const int qf = q_first + pair, tf = t_first + pair;
+    const int nq = min(counts[qf], cap), nt = min(counts[tf], cap);
+    const int nwords = (cap + 31) >> 5;
+    unsigned int* blk = tk_lds;
+    unsigned int* hist = tk_lds + nwords;
+    unsigned int* obsb = hist + 32;
+    unsigned int* tag = obsb + nwords;                                      // [cap]: per slot the latest proposal (round << 6 | 63 - lane), see below
+    int* mrow = match + (size_t)pair * cap;
+    unsigned int* acc = accepted + (size_t)pair * cap;
+    for (int w = lane; w < nwords; w += 64) {
+        unsigned int bits = 0;
+        if (t_blocked) {
+            const uint8_t* tb = t_blocked + (size_t)tf * cap;
+            const int last = max(nt - 1, 0);
+            unsigned v[32];                                                 // 32 byte loads in flight (clamped, not predicated), then the bits
+#pragma unroll
+            for (int b = 0; b < 32; ++b) v[b] = tb[min(w * 32 + b, last)];
+#pragma unroll
+            for (int b = 0; b < 32; ++b) if (w * 32 + b < nt && v[b]) bits |= 1u << b;
+        }
+        blk[w] = bits;
+        unsigned int ob = 0xFFFFFFFFu;                                      // q_obs absent: every query counts as observed
+        if (q_obs) {
+            const uint8_t* qo = q_obs + (size_t)qf * cap;
+            const int last = max(nq - 1, 0);
+            unsigned v[32];
+#pragma unroll
+            for (int b = 0; b < 32; ++b) v[b] = qo[min(w * 32 + b, last)];
+            ob = 0;
+#pragma unroll
+            for (int b = 0; b < 32; ++b) if (v[b]) ob |= 1u << b;
+        }
+        obsb[w] = ob;
+    }
+    if (lane < 32) hist[lane] = 0;
+    for (int k = lane; k < cap; k += 64) { mrow[k] = -1; tag[k] = 0; }       // ORBM_NO_MATCH
+    __syncthreads();
+    const size_t rowBase = (size_t)pair * cap;
+    int nm = 0, nacc = 0;
+    // SIXTY-FOUR queries per step, one per lane with its eight listed candidates in registers.  Every lane proposes its first candidate
+    // that is free right now; per slot the lowest lane wins (LDS atomicMax of round << 6 | 63 - lane, then a read-back).  The queries
+    // below the first loser f take their proposals at once -- none of them wanted a slot a lower query took, and everything listed before
+    // a proposal was blocked already, so this IS what the one-by-one replay (:2555-2593) does for them -- query f is resolved alone with
+    // those claims applied (its proposal is gone, or its list ran dry with more in the window: tk_rescan), and the rest of the 64 propose
+    // again.  Lists come from another XCD's writes, i.e. from memory: the next 64 queries' loads are in flight while these are resolved;
+    // the loaded values are touched only when their window becomes current, and the loads are unconditional (clamped index).
+    const int qLast = max(nq - 1, 0);
+    uint4 alo, ahi, blo, bhi;
+    int ac, bc;
+    auto fetch = [&](int qi, uint4& lo_, uint4& hi_, int& c_) {
+        const int qc = min(qi, qLast);
+        const uint4* kp = (const uint4*)(topKeys + (rowBase + qc) * TK_K);
+        lo_ = kp[0]; hi_ = kp[1];
+        c_ = topCnt[rowBase + qc];
+    };
+    fetch(lane, alo, ahi, ac);
+    unsigned int round = 1;
+    for (int W0 = 0; W0 < nq; W0 += 64) {
+        fetch(W0 + 64 + lane, blo, bhi, bc);
+        const int q = W0 + lane;
+        const bool ql = q < nq;
+        unsigned int key[TK_K] = {alo.x, alo.y, alo.z, alo.w, ahi.x, ahi.y, ahi.z, ahi.w};
+#pragma unroll
+        for (int i = 0; i < TK_K; ++i) if (!ql) key[i] = 0xFFFFFFFFu;
+        const int cnt = ql ? ac : 0;
+        const int qme = min(q, qLast);
+        const bool ob = (obsb[qme >> 5] >> (qme & 31)) & 1u;                // the lane's query has observations (:2565: only those block a slot)
+        int start = 0;
+        while (start < 64 && W0 + start < nq) {
+            unsigned int pick = 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = TK_K - 1; i >= 0; --i) {
+                const unsigned int k = key[i] & 0xFFFFu;
+                const bool fr = key[i] != 0xFFFFFFFFu && !((blk[k >> 5] >> (k & 31)) & 1u);
+                pick = fr ? key[i] : pick;
+            }
+            const bool active = ql && lane >= start;
+            const bool take = active && pick != 0xFFFFFFFFu && (pick >> 21) <= 100u;   // TH_HIGH (:2589)
+            const bool resc = active && pick == 0xFFFFFFFFu && cnt > TK_K;
+            const unsigned int pk = pick & 0xFFFFu;
+            const unsigned int tv = (round << 6) | (unsigned)(63 - lane);
+            if (take) atomicMax(&tag[pk], tv);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool lose = take && tag[pk] != tv;
+            const unsigned long long bad = __ballot(lose || resc);
+            const int f = bad ? __ffsll((long long)bad) - 1 : 64;          // >= start
+            {
+                const bool com = take && lane < f;
+                const unsigned bin = (pick >> 16) & 31u;
+                const bool withBin = com && check_ori && bin != TK_NOBIN;
+                const unsigned long long tb = __ballot(com), bb = __ballot(withBin);
+                if (com) {
+                    mrow[pk] = q;
+                    if (ob) atomicOr(&blk[pk >> 5], 1u << (pk & 31));
+                }
+                if (withBin) {
+                    acc[nacc + __popcll(bb & ((1ull << lane) - 1ull))] = pk | (bin << 16);
+                    atomicAdd(&hist[bin], 1u);
+                }
+                nm += __popcll(tb);
+                nacc += __popcll(bb);
+            }
+            if (f < 64) {
+                // query W0 + f alone (wave-uniform), the claims above applied
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int qi = W0 + f;
+                unsigned int best = 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = TK_K - 1; i >= 0; --i) {
+                    const unsigned int ki = (unsigned int)__builtin_amdgcn_readlane((int)key[i], f);
+                    const unsigned int k = ki & 0xFFFFu;
+                    const bool fr = ki != 0xFFFFFFFFu && !((blk[k >> 5] >> (k & 31)) & 1u);
+                    best = fr ? ki : best;
+                }
+                if (best == 0xFFFFFFFFu && __builtin_amdgcn_readlane(cnt, f) > TK_K)
+                    best = tk_rescan(kps, desc, cap, grid_start, grid_idx, min_x, min_y, inv_w, inv_h, qf, tf, qi, th, st, dx, dy, factor, blk, lane);
+                if (best != 0xFFFFFFFFu && (best >> 21) <= 100u) {
+                    const unsigned int k = best & 0xFFFFu, bin = (best >> 16) & 31u;
+                    const bool obs = (obsb[qi >> 5] >> (qi & 31)) & 1u;
+                    if (lane == 0) {
+                        mrow[k] = qi;
+                        if (obs) atomicOr(&blk[k >> 5], 1u << (k & 31));
+                        if (check_ori && bin != TK_NOBIN) { acc[nacc] = k | (bin << 16); atomicAdd(&hist[bin], 1u); }
+                    }
+                    ++nm;
+                    if (check_ori && bin != TK_NOBIN) ++nacc;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            start = f + 1;
+            ++round;
+        }
+        alo = blo; ahi = bhi; ac = bc;
     }
     __syncthreads();
     if (check_ori) {
