@@ -800,7 +800,7 @@ def report(wl, args, world, dt, dt_res, t_enq, gpu_wall, extra, total_kp, frames
         try:
             vj = json.load(open(os.path.join(ROOT, "profiles", name)))
             c = vj["config"]
-            if (c["width"], c["height"], c["nfeatures"]) == (W, H, nF):
+            if (c["width"], c["height"], c["nfeatures"]) == (W, H, nF) and args.texture == "dense":   # (the PMC pass ran on the dense class: FAST's count follows the corner density)
                 pp = vj["pass_per_frame"]
                 wi = (pp["resize"] + pp["fast"] + (pp["blur"] if blur_in else 0.0)) * B
                 valu = {"wave_instr_per_launch": wi, "achieved": wi / (pf_ms * 1e-3), "peak": vj["peak_wave_instr_per_s"], "unit": "wave-instr/s",

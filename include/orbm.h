@@ -258,7 +258,9 @@ int orbm_search_for_triangulation_gated(orbm_t*, int n1, const orbm_kp_t* kps1, 
  * whether its assignment blocks later queries.  The claim sequence, `bestDist <= TH_HIGH`, the rotation histogram and the
  * ComputeThreeMaxima cull (:2595-2605, 2690-2708) run in query order on the device.  Outputs (device): match [npairs][cap] =
  * query index assigned to that slot of the searched frame, ORBM_NO_MATCH or ORBM_MATCH_PRUNED -- the same row
- * orbm_search_by_projection_frame returns for the pair --, nmatches [npairs] = its return value.  Enqueue-only (capturable). */
+ * orbm_search_by_projection_frame returns for the pair --, nmatches [npairs] = its return value.  Enqueue-only (capturable;
+ * the first call with a larger batch grows the handle's scratch and must run outside a capture).  cap <= ~16 000 keypoint slots per
+ * frame (the claim replay keeps 4 B per slot in 64 KB of LDS); ORBM_E_INVALID above. */
 int orbm_search_by_projection_batch_async(orbm_t*, const orbm_kp_t* kps, const uint8_t* desc, const int32_t* counts, int cap,
                                           const int32_t* grid_start, const int32_t* grid_idx,
                                           float min_x, float min_y, float inv_w, float inv_h,
