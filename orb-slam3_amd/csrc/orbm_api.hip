@@ -1148,6 +1148,8 @@ int orbm_search_by_projection_batch_async(orbm_t* m, const orbm_kp_t* kps, const
     MHIPCHK(hipSetDevice(m->device));
     ScaleTab st;
     for (int i = 0; i < 12; ++i) st.sf[i] = i < nlevels ? sf[i] : sf[nlevels - 1];
+    const size_t lds = (size_t)(2 * ((cap + 31) >> 5) + 32 + cap) * sizeof(unsigned);   // blocked bits, rotation histogram, observed bits, proposal tags
+    if (lds > 64 * 1024) { set_merr("SearchByProjection batch: %d keypoint slots per frame need %zu B of LDS (limit 64 KB, ~16 000 slots)", cap, lds); return ORBM_E_INVALID; }
     // scratch of the handle: per query the window population and its TK_K best candidates, per pair the (slot, bin) list of the assignments
     const size_t rows = (size_t)npairs * cap;
     const size_t bCnt = (rows * sizeof(int) + 255) & ~(size_t)255, bKeys = (rows * TK_K * sizeof(unsigned) + 255) & ~(size_t)255,
@@ -1157,8 +1159,6 @@ int orbm_search_by_projection_batch_async(orbm_t* m, const orbm_kp_t* kps, const
     int* topCnt = (int*)scr; unsigned* topKeys = (unsigned*)(scr + bCnt); unsigned* acc = (unsigned*)(scr + bCnt + bKeys);
     uint4* ent = (uint4*)(scr + bCnt + bKeys + bAcc);                      // the searched frames' grid entries, packed (k_track_pack)
     const float factor = ORBM_HISTO_LENGTH / 360.0f;                        // ORBmatcher.cc:2478
-    const size_t lds = (size_t)(2 * ((cap + 31) >> 5) + 32 + cap) * sizeof(unsigned);   // blocked bits, rotation histogram, observed bits, proposal tags
-    if (lds > 64 * 1024) { set_merr("SearchByProjection batch: %d keypoint slots per frame need %zu B of LDS (limit 64 KB, ~16 000 slots)", cap, lds); return ORBM_E_INVALID; }
     MHIPCHK(rec_time(m, m->e0));
 #ifdef ORBX_AB
     if (ab_env("ORBM_TOPK_WAVE"))                                           // A/B: a wave per query

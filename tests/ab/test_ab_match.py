@@ -52,3 +52,42 @@ def test_knn2_popcount_kernel(pkg, oracle, monkeypatch, nq, nt):
     good = dg.download(np.uint8, nq)
     want = np.array([1 if (a >= 0 and b >= 0 and float(np.float32(a)) < float(np.float32(b)) * 0.7) else 0 for a, b in rdist.tolist()], np.uint8)
     assert np.array_equal(good, want)
+
+
+@pytest.mark.parametrize("knob", ["ORBM_TOPK_WAVE", "ORBM_CLAIM_V1"])
+def test_first_generation_track_kernels(pkg, oracle, synth, monkeypatch, knob):
+    """The wave-per-query top-8 kernel (k_track_topk) and the eight-queries-per-step claim replay (k_track_claim) that k_track_topk16 /
+    k_track_claim64 replaced: same final match rows as the oracle on a small batch with blocked slots and a repeated frame."""
+    import ctypes as C
+    monkeypatch.setenv(knob, "1")
+    NB = 4
+    imgs = [synth.gen_image(752, 480, 900 + i) for i in range(NB)]
+    imgs[3] = imgs[2]
+    ex = pkg.ORBextractor(1000, max_size=(752, 480), max_batch=NB)
+    res = ex.extract_batch(imgs, [(0, 1000)] * NB)
+    m = pkg.ORBmatcher(0.9)
+    OM = oracle._oracle_matcher_class()()
+    L = pkg.lib()
+    r = ex.result_device(); cap = r["cap"]
+    gs = pkg.DeviceBuffer(NB * 3073 * 4); gi = pkg.DeviceBuffer(NB * cap * 4)
+    inv_w = np.float32(64) / np.float32(752); inv_h = np.float32(48) / np.float32(480)
+    assert L.orbm_grid_build_batch_async(m.h, r["kps"], r["counts"], NB, cap, 0.0, 0.0, float(inv_w), float(inv_h), gs.ptr, gi.ptr) == 0
+    rng = np.random.default_rng(3)
+    blocked = (rng.random((NB, cap)) < 0.4).astype(np.uint8)
+    dblk = pkg.DeviceBuffer(NB * cap); dblk.upload(blocked)
+    NP = NB - 1
+    dm = pkg.DeviceBuffer(NP * cap * 4); dn = pkg.DeviceBuffer(NP * 4)
+    sf = ex.GetScaleFactors()
+    rc = L.orbm_search_by_projection_batch_async(m.h, r["kps"], r["desc"], r["counts"], cap, gs.ptr, gi.ptr, 0.0, 0.0, float(inv_w), float(inv_h),
+                                                 1, 0, NP, 30.0, sf.ctypes.data_as(C.c_void_p), 8, 1.0, 0.5, dblk.ptr, None, 1, dm.ptr, dn.ptr)
+    assert rc == 0, L.orbm_last_error()
+    m.sync()
+    match = dm.download(np.int32, NP * cap).reshape(NP, cap); nm = dn.download(np.int32, NP)
+    for p in range(NP):
+        (_, kq, dq), (_, kt, dt) = res[p + 1], res[p]
+        nq, nt = len(kq), len(kt)
+        n_ref, m_ref = OM.SearchByProjectionFrame(pkg.FrameView(kt, dt, 752, 480, backend=OM), cur_blocked=blocked[p, :nt], scale_factors=sf,
+                                                  valid=np.ones(nq, np.uint8), u=kq["x"] + np.float32(1.0), v=kq["y"] + np.float32(0.5),
+                                                  invzc=np.zeros(nq, np.float32), octave=kq["octave"], angle=kq["angle"], qdesc=dq,
+                                                  mp_obs=np.ones(nq, np.uint8), th=30.0, check_ori=True)
+        assert nm[p] == n_ref and np.array_equal(match[p, :nt], m_ref), p

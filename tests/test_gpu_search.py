@@ -548,3 +548,14 @@ def test_resident_frame_adopts_extractor_results(pkg, scene, synth):
     n_ref, m_ref = scene["OM"].SearchByProjectionFrame(view, **args)
     assert n_gpu == n_ref and np.array_equal(m_gpu, m_ref) and n_ref > 50
     res_dev.close()
+
+
+def test_batched_search_by_projection_refuses_more_slots_than_the_claim_replay_holds(pkg):
+    """k_track_claim64 keeps 4 B per keypoint slot of the searched frame in LDS (64 KB): ~16 000 slots per frame is the documented limit."""
+    m = pkg.ORBmatcher()
+    one = pkg.DeviceBuffer(256)
+    sf = np.ones(8, np.float32)
+    import ctypes as C
+    rc = m.L.orbm_search_by_projection_batch_async(m.h, one.ptr, one.ptr, one.ptr, 20000, one.ptr, one.ptr, 0.0, 0.0, 0.1, 0.1, 1, 0, 1, 15.0,
+                                                   sf.ctypes.data_as(C.c_void_p), 8, 0.0, 0.0, None, None, 1, one.ptr, one.ptr)
+    assert rc < 0 and b"LDS" in m.L.orbm_last_error()
