@@ -824,14 +824,17 @@ __device__ __forceinline__ int f4_quick(const F4Ctx& cx, const CellAux& ax, cons
 #define F3_E(w) as_us2(__builtin_amdgcn_perm(0, (w), SE))
 #define F3_O(w) as_us2(__builtin_amdgcn_perm(0, (w), SO))
 #define F3_AL(hi, lo) as_us2(__builtin_amdgcn_alignbyte(as_u32(hi), as_u32(lo), 2))   /* (lo.hi16, hi.lo16) */
-            const us2 eA = F3_E(A), oA = F3_O(A), eB0 = F3_E(B0), oB0 = F3_O(B0), eB1 = F3_E(B1),
-                      oB1 = F3_O(B1), eC = F3_E(Cw), oC = F3_O(Cw);
-            // pixel groups of the lane's 8: G0 = (0,2) G1 = (1,3) G2 = (4,6) G3 = (5,7); left = x-3, right = x+3
+            // pixel i of the lane sits at byte i of (B0, B1); left = x-3 starts at byte 1 of A, right = x+3 at byte 3 of B0.  Pairs that
+            // straddle two words come from ONE v_perm of both (selector bytes 0-3 = low word, 4-7 = high word)
+#define F3_P2(hi, lo, sel) as_us2(__builtin_amdgcn_perm((hi), (lo), (sel)))
+            const us2 oA = F3_O(A), eB0 = F3_E(B0), oB0 = F3_O(B0), eB1 = F3_E(B1), oB1 = F3_O(B1), eC = F3_E(Cw);
+            // pixel groups of the lane's 8: G0 = (0,2) G1 = (1,3) G2 = (4,6) G3 = (5,7)
             const us2 vv[4] = {eB0, oB0, eB1, oB1};
             const us2 uu[4] = {F3_E(U0), F3_O(U0), F3_E(U1), F3_O(U1)};
             const us2 dd[4] = {F3_E(D0), F3_O(D0), F3_E(D1), F3_O(D1)};
-            const us2 ll[4] = {oA, F3_AL(eB0, eA), oB0, F3_AL(eB1, eB0)};
-            const us2 rr4[4] = {F3_AL(oB1, oB0), eB1, F3_AL(oC, oB1), eC};
+            const us2 ll[4] = {oA, F3_P2(B0, A, 0x0c040c02u), oB0, F3_P2(B1, B0, 0x0c040c02u)};          // (A.1,A.3) (A.2,B0.0) (B0.1,B0.3) (B0.2,B1.0)
+            const us2 rr4[4] = {F3_P2(B1, B0, 0x0c050c03u), eB1, F3_P2(Cw, B1, 0x0c050c03u), eC};        // (B0.3,B1.1) (B1.0,B1.2) (B1.3,C.1) (C.0,C.2)
+#undef F3_P2
 #undef F3_E
 #undef F3_O
 #undef F3_AL
@@ -845,7 +848,9 @@ __device__ __forceinline__ int f4_quick(const F4Ctx& cx, const CellAux& ax, cons
             }
             const u32 Me = __builtin_amdgcn_perm(sg[2], sg[0], 0x07050301u);   // high bytes of px 0,2,4,6
             const u32 Mo = __builtin_amdgcn_perm(sg[3], sg[1], 0x07050301u);   // px 1,3,5,7
-            m = (((Me >> 4) & 0x08080808u) | (Mo & 0x80808080u)) & cur.x;
+            // even pixels' sign bits to bit 3 of each byte, odd pixels' stay at bit 7 (v_lshrrev, v_bfi, v_and: the item mask has bits 3 and 7
+            // of a byte only and clears the rest)
+            m = (((Me >> 4) & 0x08080808u) | (Mo & ~0x08080808u)) & cur.x;
         }
         // wave-inclusive prefix of popcount(m) (0..8) by a DPP scan, then each lane appends its own survivors
         const int cn = __popc(m);

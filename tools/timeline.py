@@ -6,7 +6,7 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', '').replace('orbxk::', '').replace('orbmk::', '')[:28], r['Queue_Id'])
             for r in csv.DictReader(open(f)))
-idx = [i for i, e in enumerate(ev) if 'knn2' in e[2]]
+idx = [i for i, e in enumerate(ev) if 'knn2' in e[2] or 'k_track_claim' in e[2]]   # the last kernel of a step's match leg
 a, b = idx[-3] + 1, idx[-2] + 1
 t0 = ev[a][0]
 for e in ev[a:b]:
