@@ -64,6 +64,17 @@ __device__ __forceinline__ us2 as_us2(u32 v) { return __builtin_bit_cast(us2, v)
 __device__ __forceinline__ u32 as_u32(us2 v) { return __builtin_bit_cast(u32, v); }
 __device__ __forceinline__ us2 pkmin(us2 a, us2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ us2 pkmax(us2 a, us2 b) { return __builtin_elementwise_max(a, b); }
+// three-input forms for halves in 0..255 (see fast_score16x2_tl)
+__device__ __forceinline__ us2 pkmin3(us2 a, us2 b, us2 c) {
+    u32 d;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(__builtin_bit_cast(u32, a)), "v"(__builtin_bit_cast(u32, b)), "v"(__builtin_bit_cast(u32, c)));
+    return __builtin_bit_cast(us2, d);
+}
+__device__ __forceinline__ us2 pkmax3(us2 a, us2 b, us2 c) {
+    u32 d;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(__builtin_bit_cast(u32, a)), "v"(__builtin_bit_cast(u32, b)), "v"(__builtin_bit_cast(u32, c)));
+    return __builtin_bit_cast(us2, d);
+}
 
 __device__ __forceinline__ u32 mad24(u32 a, u32 b, u32 c) {      // a*b + c on 24-bit operands, one VALU instruction
     u32 d;
@@ -309,13 +320,18 @@ __device__ __forceinline__ ss2 fast_score16x2(const u8* ta, const u8* tb, int p)
     for (int j = 0; j < 8; ++j) { m2[j] = pkmin(r[2 * j], r[2 * j + 1]); M2[j] = pkmax(r[2 * j], r[2 * j + 1]); }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { m4[j] = pkmin(m2[j], m2[(j + 1) & 7]); M4[j] = pkmax(M2[j], M2[(j + 1) & 7]); }
-    us2 bmax = us2{0, 0}, amin = us2{255, 255};
+    // three-input packed minimum / maximum (gfx950: v_pk_minimum3_f16 / v_pk_maximum3_f16).  The halves hold 0..255: as binary16 bit
+    // patterns those are non-negative subnormals, which order exactly like the integers (the kernels run with f16 denormals preserved,
+    // amdhsa_float_denorm_mode_16_64 = 3; checked against the two-input integer network on the GPU by the parity tests and the fuzz)
+    us2 u[8], U[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const us2 a = r[(2 * j + 15) & 15], c = r[(2 * j + 8) & 15];
-        bmax = pkmax(bmax, pkmin(pkmin(m4[j], m4[(j + 2) & 7]), pkmax(a, c)));
-        amin = pkmin(amin, pkmax(pkmax(M4[j], M4[(j + 2) & 7]), pkmin(a, c)));
+        u[j] = pkmin3(m4[j], m4[(j + 2) & 7], pkmax(a, c));
+        U[j] = pkmax3(M4[j], M4[(j + 2) & 7], pkmin(a, c));
     }
+    const us2 bmax = pkmax3(pkmax3(u[0], u[1], u[2]), pkmax3(u[3], u[4], u[5]), pkmax(u[6], u[7]));
+    const us2 amin = pkmin3(pkmin3(U[0], U[1], U[2]), pkmin3(U[3], U[4], U[5]), pkmin(U[6], U[7]));
     const ss2 d1 = __builtin_bit_cast(ss2, v - amin), d2 = __builtin_bit_cast(ss2, bmax - v);   // |.| <= 255: exact as signed 16-bit
     return __builtin_elementwise_max(d1, d2) - ss2{1, 1};
 }
@@ -766,13 +782,18 @@ __device__ __forceinline__ ss2 fast_score16x2_tl(u32 oa, u32 ob, int prt) {
     for (int j = 0; j < 8; ++j) { m2[j] = pkmin(r[2 * j], r[2 * j + 1]); M2[j] = pkmax(r[2 * j], r[2 * j + 1]); }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { m4[j] = pkmin(m2[j], m2[(j + 1) & 7]); M4[j] = pkmax(M2[j], M2[(j + 1) & 7]); }
-    us2 bmax = us2{0, 0}, amin = us2{255, 255};
+    // three-input packed minimum / maximum (gfx950: v_pk_minimum3_f16 / v_pk_maximum3_f16).  The halves hold 0..255: as binary16 bit
+    // patterns those are non-negative subnormals, which order exactly like the integers (the kernels run with f16 denormals preserved,
+    // amdhsa_float_denorm_mode_16_64 = 3; checked against the two-input integer network on the GPU by the parity tests and the fuzz)
+    us2 u[8], U[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const us2 a = r[(2 * j + 15) & 15], c = r[(2 * j + 8) & 15];
-        bmax = pkmax(bmax, pkmin(pkmin(m4[j], m4[(j + 2) & 7]), pkmax(a, c)));
-        amin = pkmin(amin, pkmax(pkmax(M4[j], M4[(j + 2) & 7]), pkmin(a, c)));
+        u[j] = pkmin3(m4[j], m4[(j + 2) & 7], pkmax(a, c));
+        U[j] = pkmax3(M4[j], M4[(j + 2) & 7], pkmin(a, c));
     }
+    const us2 bmax = pkmax3(pkmax3(u[0], u[1], u[2]), pkmax3(u[3], u[4], u[5]), pkmax(u[6], u[7]));
+    const us2 amin = pkmin3(pkmin3(U[0], U[1], U[2]), pkmin3(U[3], U[4], U[5]), pkmin(U[6], U[7]));
     const ss2 d1 = __builtin_bit_cast(ss2, v - amin), d2 = __builtin_bit_cast(ss2, bmax - v);   // |.| <= 255: exact as signed 16-bit
     return __builtin_elementwise_max(d1, d2) - ss2{1, 1};
 }
