@@ -76,6 +76,11 @@ __device__ __forceinline__ us2 pkmax3(us2 a, us2 b, us2 c) {
     return __builtin_bit_cast(us2, d);
 }
 
+__device__ __forceinline__ u32 ashr_pk_u8(u32 a, u32 b, u32 sh) {  // sat_u8(a >> sh) | sat_u8(b >> sh) << 8 (arithmetic shifts; upper half 0)
+    u32 d;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(sh));
+    return d;
+}
 __device__ __forceinline__ u32 mad24(u32 a, u32 b, u32 c) {      // a*b + c on 24-bit operands, one VALU instruction
     u32 d;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
@@ -243,16 +248,15 @@ __global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, in
             if (dy < yend) {
                 const RzTab ty = yt[D.rzy + dy];
                 if (ty.s + 1 == sFirst + j) {                       // rows (sy, sy+1) = (j-1, j) are both here: emit dy
-                    u32 packed = 0;
                     // (b * (H >> 4)) >> 16 as ONE v_mul_hi_u32_u24: (b << 11) * ((H >> 4) << 5) = b * (H >> 4) * 2^16, whose bits 47..32 are
                     // the wanted quotient (b <= 2048 -> 22 bits, (H >> 4) << 5 < 2^20: both operands fit 24 bits, nothing is rounded)
                     const u32 A0 = (u32)ty.a0 << 11, A1 = (u32)ty.a1 << 11;
+                    u32 sum[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        // each term is <= 1020, so (sum + 2) >> 2 <= 255: cv::resize's saturate_cast is the identity here
-                        const u32 v = (mulhi24(A0, (u32)Hp[i]) + mulhi24(A1, (u32)Hc[i]) + 2u) >> 2;
-                        packed |= v << (8 * i);
-                    }
+                    for (int i = 0; i < 4; ++i) sum[i] = mulhi24(A0, (u32)Hp[i]) + mulhi24(A1, (u32)Hc[i]) + 2u;
+                    // each term is <= 1020, so (sum + 2) >> 2 <= 255: cv::resize's saturate_cast is the identity here.  gfx950's
+                    // v_ashr_pk_u8_i32 shifts two sums and packs them as two bytes in one instruction (tools/ubench/isa_probe.hip)
+                    const u32 packed = ashr_pk_u8(sum[0], sum[1], 2u) | (ashr_pk_u8(sum[2], sum[3], 2u) << 16);
                     if (act) gstore32u(dst, (u32)(dy * D.pitch) + (u32)gcol * 4u, packed);
                     ++dy;
                 }
