@@ -431,3 +431,17 @@ def test_pyramid_level0_after_a_misaligned_device_batch(pkg, synth):
     ex(a, (0, 0))                                                          # and back: the host path is zero-copy again
     assert np.array_equal(ex.pyramid_views(0)[0], a)
     ex.close()
+
+
+def test_gfx950_instruction_semantics():
+    """The three gfx950 instructions the kernels reach through inline asm behave as the kernels assume: v_ashr_pk_u8_i32 (k_resize2's
+    shift-and-pack), v_pk_minimum3_f16 / v_pk_maximum3_f16 on 0..1023 taken as binary16 bit patterns (FAST score network: integer
+    minimum / maximum, which needs f16 denormals preserved).  tools/ubench/isa_probe.hip, built by __graft_entry__.build()."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ubench", "isa_probe")
+    if not os.path.exists(exe):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-Wno-unused-result", "-o", exe, exe + ".hip"])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "DIFFERS" not in p.stdout and p.stdout.count("\n") >= 2, p.stdout

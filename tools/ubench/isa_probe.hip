@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#define CK(x) do { if ((x) != hipSuccess) { printf("HIP error at %s\n", #x); return 2; } } while (0)
 __global__ void k_ashr(unsigned* o, const int* a, const int* b, unsigned sh, int n) {
     int i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
     unsigned r; asm volatile("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a[i]), "v"(b[i]), "v"(sh));
@@ -28,13 +29,13 @@ int main() {
         if (i < 65536) { ua[i] = (i & 255) | (((i >> 8) & 255) << 16); }
     }
     int *da, *db; unsigned *dua, *dub, *duc, *dout;
-    hipMalloc(&da, n * 4); hipMalloc(&db, n * 4); hipMalloc(&dua, n * 4); hipMalloc(&dub, n * 4); hipMalloc(&duc, n * 4); hipMalloc(&dout, 2 * n * 4);
-    hipMemcpy(da, a.data(), n * 4, hipMemcpyHostToDevice); hipMemcpy(db, b.data(), n * 4, hipMemcpyHostToDevice);
-    hipMemcpy(dua, ua.data(), n * 4, hipMemcpyHostToDevice); hipMemcpy(dub, ub.data(), n * 4, hipMemcpyHostToDevice); hipMemcpy(duc, uc.data(), n * 4, hipMemcpyHostToDevice);
+    CK(hipMalloc(&da, n * 4)); CK(hipMalloc(&db, n * 4)); CK(hipMalloc(&dua, n * 4)); CK(hipMalloc(&dub, n * 4)); CK(hipMalloc(&duc, n * 4)); CK(hipMalloc(&dout, 2 * n * 4));
+    CK(hipMemcpy(da, a.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), n * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dua, ua.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dub, ub.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(duc, uc.data(), n * 4, hipMemcpyHostToDevice));
     int bad = 0;
     for (unsigned sh : {0u, 2u, 5u}) {
         hipLaunchKernelGGL(k_ashr, dim3(n / 256), dim3(256), 0, 0, dout, da, db, sh, n);
-        hipMemcpy(o.data(), dout, n * 4, hipMemcpyDeviceToHost);
+        CK(hipMemcpy(o.data(), dout, n * 4, hipMemcpyDeviceToHost));
         for (int i = 0; i < n; ++i) {
             auto sat = [](int v) { return (unsigned)(v < 0 ? 0 : v > 255 ? 255 : v); };
             const unsigned want = sat(a[i] >> sh) | (sat(b[i] >> sh) << 8);
@@ -44,7 +45,7 @@ int main() {
     printf("v_ashr_pk_u8_i32: %s\n", bad ? "DIFFERS" : "as expected (low byte = first source, saturating, upper half zero)");
     int bad2 = 0;
     hipLaunchKernelGGL(k_m3, dim3(n / 256), dim3(256), 0, 0, dout, dua, dub, duc, n);
-    hipMemcpy(o.data(), dout, 2 * n * 4, hipMemcpyDeviceToHost);
+    CK(hipMemcpy(o.data(), dout, 2 * n * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) {
         unsigned mn = 0, mx = 0;
         for (int h = 0; h < 2; ++h) {
