@@ -2254,6 +2254,7 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
     __shared__ u32 spat[256];                                  // (x0, y0, x1, y1) per pair, int8 each (converted on use: 1 KB instead of 4 keeps 5 workgroups per CU)
     __shared__ __attribute__((aligned(16))) u8 bpatch[16 * OD_PATCH_T];   // blurred 37-row patch of each of the 16 keypoints (40- or 48-byte rows)
     __shared__ __attribute__((aligned(8))) u32 sW[OD_WTAB];   // IC_Angle byte weights (see orbx_create)
+    __shared__ unsigned long long sBal[4][16];                 // per wave: the 16 comparison ballots on their way to the lanes that store them as descriptor words
     const int tid = threadIdx.x;
     {
         for (int i = tid; i < OD_WTAB; i += 256) sW[i] = odw[i];
@@ -2315,7 +2316,8 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
                     const int idx = it * 64 + lane;
                     const int r = (idx * 171) >> 10;            // idx / 6 for idx < 256
                     const int yy = cy + r - 18, xx = xal8 + 8 * (idx - r * 6);
-                    if (r < 37) bq[k][it] = gload64u_unaligned(bl, (u32)(((__mul24(yy >> 3, Lk.btpr) + (xx >> 4)) << 7) + ((yy & 7) << 4) + (xx & 15)));
+                    // (yy >= 1: keypoints keep 19 px from the border; written as __mul24 the compiler picks a quarter-rate v_mul_lo_u32)
+                    if (r < 37) bq[k][it] = gload64u_unaligned(bl, (mad24((u32)(yy >> 3), (u32)Lk.btpr, (u32)(xx >> 4)) << 7) + (u32)(((yy & 7) << 4) + (xx & 15)));
                 }
             } else {
                 const int xalb = (cx - 18) & ~3;
@@ -2368,14 +2370,27 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
                 a2 += s2;
                 m01 += __mul24(vrow[it], (int)s2);
             }
-            int m10 = (int)a1 - 16 * (int)a2;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
-            m10s[k] = m10; m01s[k] = m01;
+            m10s[k] = (int)a1 - 16 * (int)a2; m01s[k] = m01;      // this lane's share of keypoint k's moments
         }
     }
-    const int m10 = sub == 0 ? m10s[0] : sub == 1 ? m10s[1] : sub == 2 ? m10s[2] : m10s[3];
-    const int m01 = sub == 0 ? m01s[0] : sub == 1 ? m01s[1] : sub == 2 ? m01s[2] : m01s[3];
+    // the four keypoints' moments summed over the wave so that 16-lane group g ends with keypoint g's totals: the two halves of the wave
+    // swap the two keypoints they do not keep, the quarters of a half one more, then a sum inside the 16-lane row -- 3 cross-lane
+    // moves and 4 DPP adds per moment instead of 4 x 6 butterflies (integer sums: any order is exact)
+    int m10, m01;
+    {
+        const bool hi = lane >= 32, q1 = (lane & 16) != 0;
+        auto fold = [&](const int (&v)[4]) {
+            const int keep0 = hi ? v[2] : v[0], keep1 = hi ? v[3] : v[1];
+            const int a0 = keep0 + __shfl_xor(hi ? v[0] : v[2], 32), a1_ = keep1 + __shfl_xor(hi ? v[1] : v[3], 32);
+            int x = (q1 ? a1_ : a0) + __shfl_xor(q1 ? a0 : a1_, 16);
+            x += __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false);      // row_ror:8
+            x += __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0xf, false);      // row_ror:4
+            x += __builtin_amdgcn_update_dpp(0, x, 0x122, 0xf, 0xf, false);      // row_ror:2
+            x += __builtin_amdgcn_update_dpp(0, x, 0x121, 0xf, 0xf, false);      // row_ror:1
+            return x;
+        };
+        m10 = fold(m10s); m01 = fold(m01s);
+    }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ar = angle * factorPI;
@@ -2408,13 +2423,17 @@ __global__ __launch_bounds__(256) void k_orient_desc2(Geom g, const u8* const* l
         t0[q] = (u8)lds_r8(o0);                                      // (groups without a keypoint sample their own, unwritten patch slot: in bounds, never stored)
         t1[q] = (u8)lds_r8(o1);
     }
-    u32 myword = 0;
+    // bytes 2q, 2q+1 of a keypoint's descriptor = its group's 16 bits of comparison q's ballot: lane 0 parks the 16 ballots (scalars) in
+    // LDS as they come, lane (group, sl) then picks 16-bit word `group` of ballot sl -- no per-lane shifting, masking or selecting
+    unsigned long long* sb = sBal[threadIdx.x >> 6];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const unsigned long long bal = __ballot(t0[q] < t1[q]);
-        const u32 field = (u32)(bal >> (16 * sub)) & 0xFFFFu;   // bytes 2q, 2q+1 of this group's descriptor
-        if (sl == q) myword = field;
+        if (lane == 0) sb[q] = bal;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u32 myword = ((const u16*)(sb + sl))[sub];
     if (valid) {
         const size_t row = (size_t)frame * g.kpCap + w.slot;
         ((u16*)(desc + row * 32))[sl] = (u16)myword;
