@@ -83,7 +83,6 @@ struct orbx {
     std::vector<RzTask> rzTasks[12];
     RzX4* dX4 = nullptr; RzTask* dRzTasks = nullptr; size_t capX4 = 0, capRzTasks = 0;
     int rzTaskOff[12] = {}; bool rzStream[12] = {};
-    std::vector<RzTask> rzTasksP[12]; int rzTaskOffP[12] = {}, rzShP[12] = {};   // packed variant of a level: 2 / 4 frames per wave (rzShP = 5 / 4; 0 = none)
     int64_t algBytes = 0, fusedBytes = 0;
     size_t qtLds = 0, qt2Lds = 0;
     int qtFuseD = 3;
@@ -211,7 +210,7 @@ static int build_geometry(orbx* o, int w, int h) {
     const int L = o->nlevels;
     g.nlevels = L; g.w0 = w; g.h0 = h; g.iniTh = o->iniTh; g.minTh = o->minTh; g.lowTh = std::min(o->iniTh, o->minTh);
     std::vector<Blur3Task> tiles3one;                         // one-tile k_blur3 tasks, appended behind the walks
-    o->cells.clear(); o->tiles.clear(); o->tiles3.clear(); o->b3Th.clear(); o->b3Tv.clear(); o->strips.clear(); o->f3g.clear(); o->stripTile.clear(); o->stripQ.clear(); o->xt.clear(); o->yt.clear(); o->x4.clear(); for (auto& v : o->rzTasks) v.clear(); for (auto& v : o->rzTasksP) v.clear();
+    o->cells.clear(); o->tiles.clear(); o->tiles3.clear(); o->b3Th.clear(); o->b3Tv.clear(); o->strips.clear(); o->f3g.clear(); o->stripTile.clear(); o->stripQ.clear(); o->xt.clear(); o->yt.clear(); o->x4.clear(); for (auto& v : o->rzTasks) v.clear();
     size_t off = 0, boff = 0;
     int totalSlots = 0, totalSel = 0, maxN = 0;
     int64_t sumAll = 0, sumSrc = 0, sumDst = 0;
@@ -398,22 +397,9 @@ static int build_geometry(orbx* o, int w, int h) {
                 if (o->yt[D.rzy + ye - 1].s + 2 - o->yt[D.rzy + ty].s > RZ_SRC) ok = false;
             }
             o->rzStream[l] = ok;
-            o->rzShP[l] = 0;
-            if (ok) {
+            if (ok)
                 for (int ty = 0; ty < D.h; ty += RZ_R)
                     for (int gx = 0; gx * 4 < D.w; gx += 64) o->rzTasks[l].push_back(RzTask{(short)l, (short)gx, (short)ty, 0});
-                // lanes used by 64-dword waves against 32 / 16 dwords of 2 / 4 frames per wave (levels >= 2 only: level 1 reads the
-                // caller's images through per-frame pointers)
-                const int ndw = (D.w + 3) / 4;
-                auto lanes = [&](int cw) { return ((ndw + cw - 1) / cw) * cw; };
-                int best = 64;
-                for (int cw : {32, 16}) if (lanes(cw) * 100 < lanes(best) * 95) best = cw;
-                if (l >= 2 && best != 64) {
-                    o->rzShP[l] = best == 32 ? 5 : 4;
-                    for (int ty = 0; ty < D.h; ty += RZ_R)
-                        for (int gx = 0; gx * 4 < D.w; gx += best) o->rzTasksP[l].push_back(RzTask{(short)l, (short)gx, (short)ty, 0});
-                }
-            }
         }
         while (o->xt.size() % 4) o->xt.push_back(RzTab{0, 0, 0});      // keep every level's tap offset a multiple of 4
     }
@@ -468,8 +454,6 @@ static int build_geometry(orbx* o, int w, int h) {
     {
         std::vector<RzTask> all;
         for (int l = 0; l < L; ++l) { o->rzTaskOff[l] = (int)all.size(); all.insert(all.end(), o->rzTasks[l].begin(), o->rzTasks[l].end()); }
-        for (int l = 0; l < L; ++l) { o->rzTaskOffP[l] = (int)all.size(); all.insert(all.end(), o->rzTasksP[l].begin(), o->rzTasksP[l].end()); }
-        if ((size_t)o->maxBatch * g.pyrFrameBytes >= ((size_t)1 << 32)) for (int l = 0; l < L; ++l) o->rzShP[l] = 0;   // the packed variants address frames by a 32-bit offset
         if (ensure(&o->dX4, &o->capX4, std::max<size_t>(1, o->x4.size()))) return ORBX_E_HIP;
         if (ensure(&o->dRzTasks, &o->capRzTasks, std::max<size_t>(1, all.size()))) return ORBX_E_HIP;
         if (!o->x4.empty()) HIPCHK(hipMemcpy(o->dX4, o->x4.data(), o->x4.size() * sizeof(RzX4), hipMemcpyHostToDevice));
@@ -929,17 +913,9 @@ static int extract_batch_async_impl(orbx_t* o, const uint8_t* const* imgs, int i
     STAGE_EV(7, s1);
     for (int l = 1; l < g.nlevels; ++l) {
         if (o->rzStream[l]) {
-            const int shp = o->rzShP[l], fpw = shp ? 64 >> shp : 1;
-            if (shp && nimg >= fpw) {                            // 2 / 4 frames per wave
-                const int nt = (int)o->rzTasksP[l].size();
-                auto kern = shp == 5 ? k_resize2<5> : k_resize2<4>;
-                hipLaunchKernelGGL(kern, dim3((nt + 3) / 4, (nimg + fpw - 1) / fpw), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr,
-                                   o->dRzTasks + o->rzTaskOffP[l], nt, o->dX4, o->dYt, nimg);
-            } else {
-                const int nt = (int)o->rzTasks[l].size();
-                hipLaunchKernelGGL(k_resize2<6>, dim3((nt + 3) / 4, nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr,
-                                   o->dRzTasks + o->rzTaskOff[l], nt, o->dX4, o->dYt, nimg);
-            }
+            const int nt = (int)o->rzTasks[l].size();
+            hipLaunchKernelGGL(k_resize2, dim3((nt + 3) / 4, nimg), dim3(256), 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr,
+                               o->dRzTasks + o->rzTaskOff[l], nt, o->dX4, o->dYt);
         } else {                                                 // general fallback (large scale factors)
             dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, nimg), block(64, 4);
             hipLaunchKernelGGL(k_resize, grid, block, 0, s1, g, o->dL0Ptr, l0pitch, o->dPyr, l, o->dXt, o->dYt);

@@ -197,51 +197,31 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, const u8* const* l0, int
 struct RzX4 { int bs; u8 o[4]; u32 a[4]; };                // per destination dword: byte offset of the first tap, tap offsets from it (<= 6), (2*a0 | 2*a1<<16): DOUBLED Q11 taps
 struct RzTask { short level, g0, y0, pad; };
 
-// SH = 6: a wave's 64 lanes are 64 dwords of ONE frame (blockIdx.y).  SH = 5 / 4: 32 / 16 dwords of 2 / 4 CONSECUTIVE frames -- a level
-// 131 dwords wide fills 64 + 64 + 3 lanes of three waves otherwise; frames of a batch share level, rows and taps, so control flow and
-// the scalar row tables stay wave-uniform and only a per-lane frame offset is added to the addresses (levels >= 2: source and
-// destination both live in the pyramid buffer, frame * slab bytes apart).
-template <int SH>
 __global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, int l0pitch, u8* pyr,
                                                  const RzTask* __restrict__ tasks, int ntasks,
-                                                 const RzX4* __restrict__ x4, const RzTab* __restrict__ yt, int nimg) {
+                                                 const RzX4* __restrict__ x4, const RzTab* __restrict__ yt) {
     const int lane = threadIdx.x & 63;
     const int ti = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ti >= ntasks) return;
     RzTask t = tasks[ti];
     const int level = __builtin_amdgcn_readfirstlane(t.level);
     const int g0 = __builtin_amdgcn_readfirstlane(t.g0), y0 = __builtin_amdgcn_readfirstlane(t.y0);
+    const int frame = blockIdx.y;
     const LevelDesc& D = g.lv[level];
     int sp;
-    const u8* src;
-    u8* dst;
-    u32 fo = 0;                                                  // this lane's frame offset inside the pyramid buffer (SH < 6)
-    bool fok = true;
-    int lc = lane;
-    if (SH == 6) {
-        const int frame = blockIdx.y;
-        src = level_ptr(g, l0, l0pitch, pyr, frame, level - 1, &sp);
-        dst = pyr + (size_t)frame * g.pyrFrameBytes + D.off;
-    } else {
-        const int frame = (int)blockIdx.y * (64 >> SH) + (lane >> SH);
-        fok = frame < nimg;
-        lc = lane & ((1 << SH) - 1);
-        sp = g.lv[level - 1].pitch;
-        src = pyr + g.lv[level - 1].off;
-        dst = pyr + D.off;
-        fo = (u32)min(frame, nimg - 1) * (u32)g.pyrFrameBytes;   // (host: batch x slab bytes < 4 GB for these variants)
-    }
-    const int gcol = g0 + lc;
+    const u8* src = level_ptr(g, l0, l0pitch, pyr, frame, level - 1, &sp);
+    u8* dst = pyr + (size_t)frame * g.pyrFrameBytes + D.off;
+    const int gcol = g0 + lane;
     const int ndw = (D.w + 3) >> 2;
-    const bool act = gcol < ndw && fok;
-    const RzX4 X = x4[D.rzx / 4 + (gcol < ndw ? gcol : ndw - 1)];   // rzx is the level's offset in pixels; the x4 table is per dword
+    const bool act = gcol < ndw;
+    const RzX4 X = x4[D.rzx / 4 + (act ? gcol : ndw - 1)];   // rzx is the level's offset in pixels; the x4 table is per dword
     // the 8-byte window never leaves the row's pitch: near the right edge it slides left and the selectors follow
     const int bsc = min(X.bs, sp - 8);
     const u32 delta = (u32)(X.bs - bsc);                      // 0..6; every tap index + delta stays <= 7 (taps lie inside the row)
     u32 sel[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) sel[i] = 0x0c000c00u | ((u32)X.o[i] + delta) | (((u32)X.o[i] + delta + 1u) << 16);
-    const u32 colo = (u32)bsc + fo;
+    const u32 colo = (u32)bsc;
     const int yend = min(y0 + RZ_R, D.h);
     const int sFirst = yt[D.rzy + y0].s;
     const int nsrc = yt[D.rzy + yend - 1].s + 2 - sFirst;               // host guarantees 0 <= s, s+1 < S.h, nsrc <= RZ_SRC
@@ -277,7 +257,7 @@ __global__ __launch_bounds__(256) void k_resize2(Geom g, const u8* const* l0, in
                     // each term is <= 1020, so (sum + 2) >> 2 <= 255: cv::resize's saturate_cast is the identity here.  gfx950's
                     // v_ashr_pk_u8_i32 shifts two sums and packs them as two bytes in one instruction (tools/ubench/isa_probe.hip)
                     const u32 packed = ashr_pk_u8(sum[0], sum[1], 2u) | (ashr_pk_u8(sum[2], sum[3], 2u) << 16);
-                    if (act) gstore32u(dst, fo + (u32)(dy * D.pitch) + (u32)gcol * 4u, packed);
+                    if (act) gstore32u(dst, (u32)(dy * D.pitch) + (u32)gcol * 4u, packed);
                     ++dy;
                 }
             }
